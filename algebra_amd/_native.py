@@ -1,0 +1,163 @@
+"""ctypes binding of libmalcs.so (include/malcs.h).
+
+The library is the product: there is no Python or CPU fallback.  Importing this module
+without a built `algebra_amd/libmalcs.so` raises ImportError; creating a context without a
+gfx950 device raises MalcsError.
+"""
+
+import ctypes
+import os
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libmalcs.so")
+
+MALCS_OK = 0
+PAIR_OK = 0
+PAIR_MAX_DISTANCE_EXCEEDED = 1
+
+
+class MalcsError(RuntimeError):
+    """A libmalcs call failed (message from malcs_last_error())."""
+
+
+def _load():
+    if not os.path.exists(LIB_PATH):
+        raise ImportError(
+            f"{LIB_PATH} is missing: build it with `make -C algebra_amd/csrc` "
+            "(or `python -c 'import __graft_entry__ as g; g.build()'`); algebra_amd has no CPU fallback")
+    lib = ctypes.CDLL(LIB_PATH)
+    c = ctypes
+    vp, u64, i64, i32, u32 = c.c_void_p, c.c_uint64, c.c_int64, c.c_int32, c.c_uint32
+    P = c.POINTER
+    sig = {
+        "malcs_version": (c.c_int, []),
+        "malcs_last_error": (c.c_char_p, []),
+        "malcs_device_count": (c.c_int, [P(c.c_int)]),
+        "malcs_ctx_create": (c.c_int, [c.c_int, P(vp)]),
+        "malcs_ctx_destroy": (c.c_int, [vp]),
+        "malcs_ctx_sync": (c.c_int, [vp]),
+        "malcs_ctx_device_info": (c.c_int, [vp, c.c_char_p, c.c_int, P(c.c_int), P(c.c_int)]),
+        "malcs_batch_create": (c.c_int, [vp, vp, u64, vp, vp, vp, vp, u64, c.c_int, P(vp)]),
+        "malcs_batch_destroy": (c.c_int, [vp]),
+        "malcs_batch_size": (u64, [vp]),
+        "malcs_edit_distance_launch": (c.c_int, [vp]),
+        "malcs_edit_distance_fetch": (c.c_int, [vp, vp]),
+        "malcs_edit_distance_time": (c.c_int, [vp, c.c_int, P(c.c_float)]),
+        "malcs_edit_distance_batch": (c.c_int, [vp, vp, u64, vp, vp, vp, vp, u64, c.c_int, vp]),
+        "malcs_lcs_graph_batch": (c.c_int, [vp, vp, vp, P(vp)]),
+        "malcs_graphs_destroy": (c.c_int, [vp]),
+        "malcs_graphs_counts": (c.c_int, [vp, vp]),
+        "malcs_graphs_status": (c.c_int, [vp, vp, vp]),
+        "malcs_graphs_supremal": (c.c_int, [vp, vp]),
+        "malcs_graphs_runs": (c.c_int, [vp, u64, vp]),
+        "malcs_graphs_nodes": (c.c_int, [vp, u64, vp]),
+        "malcs_graphs_edges": (c.c_int, [vp, u64, vp]),
+        "malcs_graphs_timing": (c.c_int, [vp, vp]),
+    }
+    for name, (res, args) in sig.items():
+        fn = getattr(lib, name)          # AttributeError here = header and library disagree
+        fn.restype = res
+        fn.argtypes = args
+    return lib, sorted(sig)
+
+
+lib, EXPORTS = _load()
+
+
+def check(rc):
+    if rc != MALCS_OK:
+        raise MalcsError(f"libmalcs error {rc}: {lib.malcs_last_error().decode()}")
+
+
+def ptr(array):
+    return array.ctypes.data_as(ctypes.c_void_p)
+
+
+class Context:
+    """One libmalcs context = one GPU (one process per GPU)."""
+
+    def __init__(self, device=0):
+        self.handle = ctypes.c_void_p()
+        check(lib.malcs_ctx_create(int(device), ctypes.byref(self.handle)))
+        self.device = int(device)
+
+    def close(self):
+        if self.handle:
+            lib.malcs_ctx_destroy(self.handle)
+            self.handle = ctypes.c_void_p()
+
+    def sync(self):
+        check(lib.malcs_ctx_sync(self.handle))
+
+    def device_info(self):
+        name = ctypes.create_string_buffer(256)
+        cus, mhz = ctypes.c_int(), ctypes.c_int()
+        check(lib.malcs_ctx_device_info(self.handle, name, 256, ctypes.byref(cus), ctypes.byref(mhz)))
+        return name.value.decode(), cus.value, mhz.value
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+_default_ctx = None
+
+
+def default_context():
+    """Context on the device this process owns (LOCAL_RANK, else MALCS_DEVICE, else 0)."""
+    global _default_ctx
+    if _default_ctx is None:
+        device = int(os.environ.get("MALCS_DEVICE", os.environ.get("LOCAL_RANK", "0")))
+        _default_ctx = Context(device)
+    return _default_ctx
+
+
+class Batch:
+    """Sequence pairs resident in HBM (malcs_batch)."""
+
+    def __init__(self, ctx, syms, a_off, a_len, b_off, b_len, n_symbols):
+        self.ctx = ctx
+        syms = np.ascontiguousarray(syms, dtype=np.uint8)
+        a_off = np.ascontiguousarray(a_off, dtype=np.uint64)
+        b_off = np.ascontiguousarray(b_off, dtype=np.uint64)
+        a_len = np.ascontiguousarray(a_len, dtype=np.uint32)
+        b_len = np.ascontiguousarray(b_len, dtype=np.uint32)
+        n = len(a_off)
+        if not (len(a_len) == len(b_off) == len(b_len) == n):
+            raise ValueError("offset/length arrays differ in length")
+        self.n_pairs = n
+        self.handle = ctypes.c_void_p()
+        check(lib.malcs_batch_create(ctx.handle, ptr(syms), syms.size, ptr(a_off), ptr(a_len), ptr(b_off), ptr(b_len),
+                                     n, int(n_symbols), ctypes.byref(self.handle)))
+
+    def close(self):
+        if self.handle:
+            lib.malcs_batch_destroy(self.handle)
+            self.handle = ctypes.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def launch_distances(self):
+        check(lib.malcs_edit_distance_launch(self.handle))
+
+    def fetch_distances(self):
+        out = np.empty(self.n_pairs, dtype=np.int32)
+        check(lib.malcs_edit_distance_fetch(self.handle, ptr(out)))
+        return out
+
+    def distances(self):
+        self.launch_distances()
+        return self.fetch_distances()
+
+    def time_distances(self, iters):
+        ms = ctypes.c_float()
+        check(lib.malcs_edit_distance_time(self.handle, int(iters), ctypes.byref(ms)))
+        return ms.value

@@ -1,0 +1,261 @@
+// malcs_api.cpp -- the C-ABI of libmalcs (include/malcs.h): contexts, batches, family-1 entry points.
+#include "malcs_internal.hpp"
+#include <cstdarg>
+#include <cstring>
+#include <new>
+#include <unordered_map>
+
+static thread_local char g_last_error[512] = "";
+
+void malcs_set_error(const char *fmt, ...)
+{
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_last_error, sizeof(g_last_error), fmt, ap);
+    va_end(ap);
+}
+
+extern "C" {
+
+int malcs_version(void) { return MALCS_VERSION; }
+const char *malcs_last_error(void) { return g_last_error; }
+
+int malcs_device_count(int *count)
+{
+    if (!count) { malcs_set_error("count is NULL"); return MALCS_ERR_ARG; }
+    int n = 0;
+    hipError_t e = hipGetDeviceCount(&n);
+    if (e != hipSuccess) { *count = 0; malcs_set_error("hipGetDeviceCount: %s", hipGetErrorString(e)); return MALCS_ERR_HIP; }
+    *count = n;
+    return MALCS_OK;
+}
+
+int malcs_ctx_create(int device, malcs_ctx **out)
+{
+    if (!out) { malcs_set_error("ctx is NULL"); return MALCS_ERR_ARG; }
+    *out = nullptr;
+    int n = 0;
+    hipError_t e = hipGetDeviceCount(&n);
+    if (e != hipSuccess || n == 0) {
+        malcs_set_error("no HIP device available (%s); libmalcs has no CPU fallback",
+                        e != hipSuccess ? hipGetErrorString(e) : "device count 0");
+        return MALCS_ERR_HIP;
+    }
+    if (device < 0 || device >= n) { malcs_set_error("device %d out of range [0,%d)", device, n); return MALCS_ERR_ARG; }
+    malcs_ctx *c = new (std::nothrow) malcs_ctx();
+    if (!c) { malcs_set_error("out of host memory"); return MALCS_ERR_NOMEM; }
+    c->device = device;
+    MALCS_HIP(hipSetDevice(device));
+    MALCS_HIP(hipGetDeviceProperties(&c->prop, device));
+    if (strncmp(c->prop.gcnArchName, "gfx950", 6) != 0) {
+        malcs_set_error("device %d is %s; libmalcs is built for gfx950 only", device, c->prop.gcnArchName);
+        delete c;
+        return MALCS_ERR_HIP;
+    }
+    MALCS_HIP(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
+    MALCS_HIP(hipEventCreate(&c->ev0));
+    MALCS_HIP(hipEventCreate(&c->ev1));
+    MALCS_HIP(hipEventCreate(&c->ev2));
+    *out = c;
+    return MALCS_OK;
+}
+
+int malcs_ctx_destroy(malcs_ctx *c)
+{
+    if (!c) return MALCS_OK;
+    hipSetDevice(c->device);
+    if (c->stream) hipStreamSynchronize(c->stream);
+    if (c->ev0) hipEventDestroy(c->ev0);
+    if (c->ev1) hipEventDestroy(c->ev1);
+    if (c->ev2) hipEventDestroy(c->ev2);
+    if (c->stream) hipStreamDestroy(c->stream);
+    delete c;
+    return MALCS_OK;
+}
+
+int malcs_ctx_sync(malcs_ctx *c)
+{
+    if (!c) { malcs_set_error("ctx is NULL"); return MALCS_ERR_ARG; }
+    MALCS_HIP(hipSetDevice(c->device));
+    MALCS_HIP(hipStreamSynchronize(c->stream));
+    return MALCS_OK;
+}
+
+int malcs_ctx_device_info(malcs_ctx *c, char *name, int name_cap, int *cus, int *clock_mhz)
+{
+    if (!c) { malcs_set_error("ctx is NULL"); return MALCS_ERR_ARG; }
+    if (name && name_cap > 0) snprintf(name, (size_t)name_cap, "%s (%s)", c->prop.name, c->prop.gcnArchName);
+    if (cus) *cus = c->prop.multiProcessorCount;
+    if (clock_mhz) *clock_mhz = c->prop.clockRate / 1000;
+    return MALCS_OK;
+}
+
+static int planes_for(int n_symbols)
+{
+    if (n_symbols <= 4) return 2;
+    if (n_symbols <= 8) return 3;
+    if (n_symbols <= 16) return 4;
+    return 8;
+}
+
+static void batch_release(malcs_batch *b)
+{
+    if (!b) return;
+    hipSetDevice(b->ctx->device);
+    hipFree(b->d_planes); hipFree(b->d_a_off); hipFree(b->d_a_len); hipFree(b->d_b_off); hipFree(b->d_b_len);
+    hipFree(b->d_order); hipFree(b->d_dist);
+    delete b;
+}
+
+static int batch_build(malcs_ctx *ctx, const uint8_t *syms, uint64_t n_syms,
+                       const uint64_t *a_off, const uint32_t *a_len, const uint64_t *b_off, const uint32_t *b_len,
+                       uint64_t n_pairs, int n_symbols, malcs_batch *b)
+{
+    b->ctx = ctx;
+    b->n_pairs = n_pairs;
+    b->n_planes = planes_for(n_symbols);
+    const uint32_t NP = (uint32_t)b->n_planes;
+
+    // distinct sequences (pairs may share them: a relation-matrix tile re-uses every window many times)
+    struct key { uint64_t off; uint32_t len; bool operator==(const key &o) const { return off == o.off && len == o.len; } };
+    struct key_hash { size_t operator()(const key &k) const { return (size_t)(k.off * 0x9e3779b97f4a7c15ull) ^ ((size_t)k.len * 0xc2b2ae3d27d4eb4full); } };
+    std::unordered_map<key, uint32_t, key_hash> index;
+    index.reserve((size_t)n_pairs * 2 + 1);
+    std::vector<uint64_t> seq_byte_off;
+    std::vector<uint32_t> seq_len, seq_blk_off;
+    uint64_t total_blocks = 0;
+    auto intern = [&](uint64_t off, uint32_t len, uint32_t *id) -> int {
+        if (off > n_syms || (uint64_t)len > n_syms - off) { malcs_set_error("sequence [%llu,+%u) outside the symbol buffer of %llu bytes", (unsigned long long)off, len, (unsigned long long)n_syms); return MALCS_ERR_ARG; }
+        key k{off, len};
+        auto it = index.find(k);
+        if (it != index.end()) { *id = it->second; return MALCS_OK; }
+        *id = (uint32_t)seq_len.size();
+        index.emplace(k, *id);
+        seq_byte_off.push_back(off);
+        seq_len.push_back(len);
+        seq_blk_off.push_back((uint32_t)total_blocks);
+        total_blocks += (len + 31u) / 32u;
+        return MALCS_OK;
+    };
+    b->a_off.resize(n_pairs); b->a_len.resize(n_pairs); b->b_off.resize(n_pairs); b->b_len.resize(n_pairs);
+    b->max_len = 0;
+    for (uint64_t i = 0; i < n_pairs; i++) {
+        uint32_t ia, ib;
+        int rc = intern(a_off[i], a_len[i], &ia);
+        if (rc) return rc;
+        rc = intern(b_off[i], b_len[i], &ib);
+        if (rc) return rc;
+        if (total_blocks * NP >= 0xffffffffull) { malcs_set_error("batch needs more than 16 GiB of packed planes; split it"); return MALCS_ERR_TOO_LONG; }
+        b->a_off[i] = seq_blk_off[ia] * NP; b->a_len[i] = a_len[i];
+        b->b_off[i] = seq_blk_off[ib] * NP; b->b_len[i] = b_len[i];
+        if (a_len[i] > b->max_len) b->max_len = a_len[i];
+        if (b_len[i] > b->max_len) b->max_len = b_len[i];
+    }
+    const uint32_t n_seqs = (uint32_t)seq_len.size();
+    b->arena_dwords = total_blocks * NP;
+
+    MALCS_HIP(hipSetDevice(ctx->device));
+    hipStream_t st = ctx->stream;
+    uint8_t *d_syms = nullptr; uint64_t *d_sbo = nullptr; uint32_t *d_sl = nullptr, *d_sko = nullptr;
+    if (n_pairs) {
+        MALCS_HIP(hipMalloc(&b->d_planes, (b->arena_dwords + 4) * sizeof(uint32_t)));
+        MALCS_HIP(hipMalloc(&b->d_a_off, n_pairs * 4)); MALCS_HIP(hipMalloc(&b->d_a_len, n_pairs * 4));
+        MALCS_HIP(hipMalloc(&b->d_b_off, n_pairs * 4)); MALCS_HIP(hipMalloc(&b->d_b_len, n_pairs * 4));
+        MALCS_HIP(hipMalloc(&b->d_dist, n_pairs * 4));
+        MALCS_HIP(hipMemcpyAsync(b->d_a_off, b->a_off.data(), n_pairs * 4, hipMemcpyHostToDevice, st));
+        MALCS_HIP(hipMemcpyAsync(b->d_a_len, b->a_len.data(), n_pairs * 4, hipMemcpyHostToDevice, st));
+        MALCS_HIP(hipMemcpyAsync(b->d_b_off, b->b_off.data(), n_pairs * 4, hipMemcpyHostToDevice, st));
+        MALCS_HIP(hipMemcpyAsync(b->d_b_len, b->b_len.data(), n_pairs * 4, hipMemcpyHostToDevice, st));
+        if (total_blocks) {
+            MALCS_HIP(hipMalloc(&d_syms, n_syms ? n_syms : 1));
+            MALCS_HIP(hipMalloc(&d_sbo, (size_t)n_seqs * 8)); MALCS_HIP(hipMalloc(&d_sl, (size_t)n_seqs * 4)); MALCS_HIP(hipMalloc(&d_sko, (size_t)n_seqs * 4));
+            MALCS_HIP(hipMemcpyAsync(d_syms, syms, n_syms, hipMemcpyHostToDevice, st));
+            MALCS_HIP(hipMemcpyAsync(d_sbo, seq_byte_off.data(), (size_t)n_seqs * 8, hipMemcpyHostToDevice, st));
+            MALCS_HIP(hipMemcpyAsync(d_sl, seq_len.data(), (size_t)n_seqs * 4, hipMemcpyHostToDevice, st));
+            MALCS_HIP(hipMemcpyAsync(d_sko, seq_blk_off.data(), (size_t)n_seqs * 4, hipMemcpyHostToDevice, st));
+            int rc = malcs_pack_launch(ctx, d_syms, d_sbo, d_sl, d_sko, n_seqs, (uint32_t)total_blocks, b->n_planes, b->d_planes);
+            if (rc) return rc;
+        }
+        MALCS_HIP(hipStreamSynchronize(st));
+        hipFree(d_syms); hipFree(d_sbo); hipFree(d_sl); hipFree(d_sko);
+    }
+    return malcs_dist_plan(b);
+}
+
+int malcs_batch_create(malcs_ctx *ctx, const uint8_t *syms, uint64_t n_syms,
+                       const uint64_t *a_off, const uint32_t *a_len, const uint64_t *b_off, const uint32_t *b_len,
+                       uint64_t n_pairs, int n_symbols, malcs_batch **out)
+{
+    if (!out) { malcs_set_error("batch is NULL"); return MALCS_ERR_ARG; }
+    *out = nullptr;
+    if (!ctx) { malcs_set_error("ctx is NULL"); return MALCS_ERR_ARG; }
+    if (n_pairs && (!a_off || !a_len || !b_off || !b_len)) { malcs_set_error("offset/length arrays are NULL"); return MALCS_ERR_ARG; }
+    if (n_syms && !syms) { malcs_set_error("syms is NULL"); return MALCS_ERR_ARG; }
+    if (n_symbols < 1 || n_symbols > 256) { malcs_set_error("n_symbols %d outside [1,256]", n_symbols); return MALCS_ERR_ARG; }
+    if (n_pairs >= 0x7fffffffull) { malcs_set_error("too many pairs in one batch"); return MALCS_ERR_ARG; }
+    malcs_batch *b = new (std::nothrow) malcs_batch();
+    if (!b) { malcs_set_error("out of host memory"); return MALCS_ERR_NOMEM; }
+    int rc = batch_build(ctx, syms, n_syms, a_off, a_len, b_off, b_len, n_pairs, n_symbols, b);
+    if (rc) { batch_release(b); return rc; }
+    *out = b;
+    return MALCS_OK;
+}
+
+int malcs_batch_destroy(malcs_batch *b)
+{
+    if (!b) return MALCS_OK;
+    hipSetDevice(b->ctx->device);
+    hipStreamSynchronize(b->ctx->stream);
+    batch_release(b);
+    return MALCS_OK;
+}
+
+uint64_t malcs_batch_size(const malcs_batch *b) { return b ? b->n_pairs : 0; }
+
+int malcs_edit_distance_launch(malcs_batch *b)
+{
+    if (!b) { malcs_set_error("batch is NULL"); return MALCS_ERR_ARG; }
+    MALCS_HIP(hipSetDevice(b->ctx->device));
+    return malcs_dist_launch(b);
+}
+
+int malcs_edit_distance_fetch(malcs_batch *b, int32_t *dist)
+{
+    if (!b || (!dist && b->n_pairs)) { malcs_set_error("NULL argument"); return MALCS_ERR_ARG; }
+    MALCS_HIP(hipSetDevice(b->ctx->device));
+    if (b->n_pairs)
+        MALCS_HIP(hipMemcpyAsync(dist, b->d_dist, b->n_pairs * sizeof(int32_t), hipMemcpyDeviceToHost, b->ctx->stream));
+    MALCS_HIP(hipStreamSynchronize(b->ctx->stream));
+    return MALCS_OK;
+}
+
+int malcs_edit_distance_time(malcs_batch *b, int iters, float *ms_total)
+{
+    if (!b || !ms_total || iters < 1) { malcs_set_error("bad argument"); return MALCS_ERR_ARG; }
+    malcs_ctx *c = b->ctx;
+    MALCS_HIP(hipSetDevice(c->device));
+    MALCS_HIP(hipEventRecord(c->ev0, c->stream));
+    for (int i = 0; i < iters; i++) {
+        int rc = malcs_dist_launch(b);
+        if (rc) return rc;
+    }
+    MALCS_HIP(hipEventRecord(c->ev1, c->stream));
+    MALCS_HIP(hipEventSynchronize(c->ev1));
+    MALCS_HIP(hipEventElapsedTime(ms_total, c->ev0, c->ev1));
+    return MALCS_OK;
+}
+
+int malcs_edit_distance_batch(malcs_ctx *ctx, const uint8_t *syms, uint64_t n_syms,
+                              const uint64_t *a_off, const uint32_t *a_len, const uint64_t *b_off, const uint32_t *b_len,
+                              uint64_t n_pairs, int n_symbols, int32_t *dist)
+{
+    malcs_batch *b = nullptr;
+    int rc = malcs_batch_create(ctx, syms, n_syms, a_off, a_len, b_off, b_len, n_pairs, n_symbols, &b);
+    if (rc) return rc;
+    rc = malcs_edit_distance_launch(b);
+    if (!rc) rc = malcs_edit_distance_fetch(b, dist);
+    malcs_batch_destroy(b);
+    return rc;
+}
+
+}  // extern "C"

@@ -1,0 +1,132 @@
+/*
+ * malcs.h -- C-ABI of libmalcs.so: the MI355X (gfx950) backend for the LCS hot path of
+ * mutalyzer/algebra (algebra/lcs: edit_distance, LCSgraph).
+ *
+ * The reference has no FFI layer: its boundary for this path is the Python module API of
+ * `algebra.lcs` (algebra/lcs/__init__.py:4-11).  Every entry point below names the reference
+ * function it stands in for (paths relative to the reference checkout).  The Python facade
+ * `algebra_amd.lcs` binds these symbols with ctypes and keeps the reference's names, argument
+ * meaning and exceptions; INTEGRATION.md shows the stub a maintainer adds to algebra/lcs.
+ *
+ * Conventions
+ *   - plain pointers and sizes only; all buffers are caller-allocated and caller-owned unless a
+ *     handle type says otherwise; handles are freed with their *_destroy function.
+ *   - every function returns MALCS_OK (0) or a negative error code; malcs_last_error() returns a
+ *     thread-local human-readable message for the last failure on the calling thread.
+ *   - symbols are opaque uint8 codes compared for equality only (the reference compares str code
+ *     points with ==, algebra/lcs/edit_distance.py:26); `n_symbols` is an exclusive upper bound
+ *     on the codes in a batch (DNA: 4) and selects the number of bit planes on the device.
+ *   - there is no CPU fallback: without a usable HIP device every compute entry point fails
+ *     with MALCS_ERR_HIP.
+ *   - one process per GPU: a context is bound to one device; calls on one context are
+ *     serialised by the caller.
+ */
+#ifndef MALCS_H
+#define MALCS_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define MALCS_VERSION 100           /* 0.1.0 */
+
+#define MALCS_OK 0
+#define MALCS_ERR_ARG (-1)          /* bad argument */
+#define MALCS_ERR_NOMEM (-2)        /* host or device allocation failed */
+#define MALCS_ERR_HIP (-3)          /* HIP runtime error / no device */
+#define MALCS_ERR_TOO_LONG (-4)     /* a sequence exceeds what the kernels support */
+#define MALCS_ERR_INTERNAL (-5)
+
+/* per-pair status values written by malcs_lcs_graph_batch */
+#define MALCS_PAIR_OK 0
+#define MALCS_PAIR_MAX_DISTANCE_EXCEEDED 1   /* -> ValueError("maximum distance exceeded"), lcs_graph.py:345-346 */
+
+typedef struct malcs_ctx malcs_ctx;
+typedef struct malcs_batch malcs_batch;
+typedef struct malcs_graphs malcs_graphs;
+
+/* ---- library / context ----------------------------------------------------------------- */
+
+int malcs_version(void);
+const char *malcs_last_error(void);
+int malcs_device_count(int *count);
+
+/* Bind a context (stream, scratch) to HIP device `device`. */
+int malcs_ctx_create(int device, malcs_ctx **ctx);
+int malcs_ctx_destroy(malcs_ctx *ctx);
+int malcs_ctx_sync(malcs_ctx *ctx);
+/* Device name / CU count / clock (MHz), for bench reports. */
+int malcs_ctx_device_info(malcs_ctx *ctx, char *name, int name_cap, int *cus, int *clock_mhz);
+
+/* ---- batches: sequence pairs resident in HBM ---------------------------------------------
+ * `syms` holds all sequences back to back; pair i is (syms[a_off[i] .. +a_len[i]),
+ * syms[b_off[i] .. +b_len[i])) = (reference window, observed window).  The call copies the
+ * bytes to the device, packs them into bit planes there and returns; the host buffers may be
+ * reused immediately.  Pairs may share sequences (same offsets). */
+int malcs_batch_create(malcs_ctx *ctx, const uint8_t *syms, uint64_t n_syms,
+                       const uint64_t *a_off, const uint32_t *a_len,
+                       const uint64_t *b_off, const uint32_t *b_len,
+                       uint64_t n_pairs, int n_symbols, malcs_batch **batch);
+int malcs_batch_destroy(malcs_batch *batch);
+uint64_t malcs_batch_size(const malcs_batch *batch);
+
+/* ---- kernel family 1: batched distances ---------------------------------------------------
+ * Stands in for edit_distance(a, b) (algebra/lcs/edit_distance.py:21-53):
+ * dist[i] = a_len[i] + b_len[i] - 2 * LLCS(a_i, b_i).
+ *
+ * _launch enqueues the kernels on the context's stream and returns; the distances stay in HBM.
+ * _fetch waits for them and copies them to `dist` (n_pairs int32).  _time runs `iters`
+ * back-to-back launches between two HIP events on that stream and reports the elapsed
+ * milliseconds (inputs and outputs device-resident; this is what bench.py times). */
+int malcs_edit_distance_launch(malcs_batch *batch);
+int malcs_edit_distance_fetch(malcs_batch *batch, int32_t *dist);
+int malcs_edit_distance_time(malcs_batch *batch, int iters, float *ms_total);
+
+/* One-shot convenience: create + launch + fetch + destroy. */
+int malcs_edit_distance_batch(malcs_ctx *ctx, const uint8_t *syms, uint64_t n_syms,
+                              const uint64_t *a_off, const uint32_t *a_len,
+                              const uint64_t *b_off, const uint32_t *b_len,
+                              uint64_t n_pairs, int n_symbols, int32_t *dist);
+
+/* ---- kernel family 2: batched LCS graphs ----------------------------------------------------
+ * Stands in for LCSgraph.__init__(reference, observed, shift, max_distance)
+ * (algebra/lcs/lcs_graph.py:59-61) = _lcs_nodes (:238-348) + _build_graph (:351-453), for every
+ * pair of the batch.  `shift` and `max_distance` may be NULL (all 0 / no limit; a max_distance
+ * of 0 means no limit, as in the reference, :345).
+ *
+ * The device computes the distance and the optimal maximal match runs (row, col, length, level);
+ * the host part of the library orders them as the reference's sweep does and compresses them
+ * into the graph exactly as _build_graph does.  Results are held by the returned handle.
+ *
+ * Per pair i the handle exposes
+ *   status     MALCS_PAIR_*                      distance   graph.distance
+ *   supremal   {start, end, obs_from, obs_to}    graph.supremal = Variant(start, end, observed[obs_from:obs_to])
+ *   runs       n_runs x {row, col, length, level}, sorted as the reference's level lists
+ *              (shifted coordinates, as LCSgraph.Node)
+ *   nodes      n_nodes x {row, col, length}      node 0 is graph._source; numbering = BFS by
+ *                                                identity from the source following edge order
+ *   edges      n_edges x {src, dst, start, end, obs_from, obs_to}, grouped by src in node order and,
+ *              within a node, in the order of Node.edges; the edge's variant is
+ *              Variant(start, end, observed[obs_from:obs_to])
+ */
+int malcs_lcs_graph_batch(malcs_batch *batch, const int64_t *shift, const int64_t *max_distance,
+                          malcs_graphs **graphs);
+int malcs_graphs_destroy(malcs_graphs *graphs);
+/* per-pair sizes: counts[4*i + {0,1,2,3}] = {n_runs, n_levels, n_nodes, n_edges} */
+int malcs_graphs_counts(const malcs_graphs *graphs, int64_t *counts);
+int malcs_graphs_status(const malcs_graphs *graphs, int32_t *status, int64_t *distance);
+int malcs_graphs_supremal(const malcs_graphs *graphs, int64_t *supremal4);
+/* fill caller buffers for pair i (sizes from malcs_graphs_counts) */
+int malcs_graphs_runs(const malcs_graphs *graphs, uint64_t i, int64_t *runs4);
+int malcs_graphs_nodes(const malcs_graphs *graphs, uint64_t i, int64_t *nodes3);
+int malcs_graphs_edges(const malcs_graphs *graphs, uint64_t i, int64_t *edges6);
+/* timing split of the last malcs_lcs_graph_batch on this handle, milliseconds:
+ * out[0] forward DP kernel, out[1] reach/extract kernel (HIP events), out[2] D2H + host graph build */
+int malcs_graphs_timing(const malcs_graphs *graphs, float *out3);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* MALCS_H */
