@@ -5,8 +5,10 @@ without a built `algebra_amd/libmalcs.so` raises ImportError; creating a context
 gfx950 device raises MalcsError.
 """
 
+import atexit
 import ctypes
 import os
+import weakref
 
 import numpy as np
 
@@ -66,6 +68,21 @@ def _load():
 lib, EXPORTS = _load()
 
 
+# Handles still open at interpreter exit are released here, in dependency order, while the HIP
+# runtime is still alive (its own teardown runs after Python's).
+_live = {"graphs": weakref.WeakSet(), "batch": weakref.WeakSet(), "ctx": weakref.WeakSet()}
+
+
+@atexit.register
+def _close_all():
+    for kind in ("graphs", "batch", "ctx"):
+        for obj in list(_live[kind]):
+            try:
+                obj.close()
+            except Exception:
+                pass
+
+
 def check(rc):
     if rc != MALCS_OK:
         raise MalcsError(f"libmalcs error {rc}: {lib.malcs_last_error().decode()}")
@@ -82,6 +99,7 @@ class Context:
         self.handle = ctypes.c_void_p()
         check(lib.malcs_ctx_create(int(device), ctypes.byref(self.handle)))
         self.device = int(device)
+        _live["ctx"].add(self)
 
     def close(self):
         if self.handle:
@@ -133,10 +151,12 @@ class Batch:
         self.handle = ctypes.c_void_p()
         check(lib.malcs_batch_create(ctx.handle, ptr(syms), syms.size, ptr(a_off), ptr(a_len), ptr(b_off), ptr(b_len),
                                      n, int(n_symbols), ctypes.byref(self.handle)))
+        _live["batch"].add(self)
 
     def close(self):
         if self.handle:
-            lib.malcs_batch_destroy(self.handle)
+            if self.ctx.handle:          # a batch outliving its context is leaked, not freed through it
+                lib.malcs_batch_destroy(self.handle)
             self.handle = ctypes.c_void_p()
 
     def __del__(self):
@@ -161,3 +181,64 @@ class Batch:
         ms = ctypes.c_float()
         check(lib.malcs_edit_distance_time(self.handle, int(iters), ctypes.byref(ms)))
         return ms.value
+
+    def graphs(self, shift=None, max_distance=None):
+        """LCSgraph(reference_i, observed_i, shift_i, max_distance_i) for every pair."""
+        sh = md = None
+        if shift is not None:
+            sh = np.ascontiguousarray(shift, dtype=np.int64)
+        if max_distance is not None:
+            md = np.ascontiguousarray(max_distance, dtype=np.int64)
+        handle = ctypes.c_void_p()
+        check(lib.malcs_lcs_graph_batch(self.handle, ptr(sh) if sh is not None else None,
+                                        ptr(md) if md is not None else None, ctypes.byref(handle)))
+        return Graphs(handle, self.n_pairs)
+
+
+class Graphs:
+    """Result handle of malcs_lcs_graph_batch, read out into numpy arrays."""
+
+    def __init__(self, handle, n_pairs):
+        self.handle = handle
+        self.n_pairs = n_pairs
+        _live["graphs"].add(self)
+        try:
+            self.counts = np.zeros((n_pairs, 4), dtype=np.int64)
+            self.status = np.zeros(n_pairs, dtype=np.int32)
+            self.distance = np.zeros(n_pairs, dtype=np.int64)
+            self.supremal = np.zeros((n_pairs, 4), dtype=np.int64)
+            self.timing = np.zeros(3, dtype=np.float32)
+            if n_pairs:
+                check(lib.malcs_graphs_counts(handle, ptr(self.counts)))
+                check(lib.malcs_graphs_status(handle, ptr(self.status), ptr(self.distance)))
+                check(lib.malcs_graphs_supremal(handle, ptr(self.supremal)))
+            check(lib.malcs_graphs_timing(handle, ptr(self.timing)))
+        except Exception:
+            self.close()
+            raise
+
+    def runs(self, i):
+        out = np.zeros((int(self.counts[i, 0]), 4), dtype=np.int64)
+        check(lib.malcs_graphs_runs(self.handle, i, ptr(out)))
+        return out
+
+    def nodes(self, i):
+        out = np.zeros((int(self.counts[i, 2]), 3), dtype=np.int64)
+        check(lib.malcs_graphs_nodes(self.handle, i, ptr(out)))
+        return out
+
+    def edges(self, i):
+        out = np.zeros((int(self.counts[i, 3]), 6), dtype=np.int64)
+        check(lib.malcs_graphs_edges(self.handle, i, ptr(out)))
+        return out
+
+    def close(self):
+        if self.handle:
+            lib.malcs_graphs_destroy(self.handle)
+            self.handle = ctypes.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass

@@ -1,13 +1,498 @@
-// placeholder until family 2 lands (replaced in the next commit)
+// malcs_build.cpp -- host half of family 2: drives the two device passes, turns the device's
+// run-boundary events into level-ordered runs and compresses them into the LCS graph.
+//
+// Reference behaviour restated here (paths relative to the reference checkout):
+//   * ordering of runs inside a level = order in which the O(NP) sweep of _lcs_nodes meets them
+//     (algebra/lcs/lcs_graph.py:335-342: diagonals below delta ascending, above delta descending,
+//     delta last, iteration by iteration; within a diagonal by position) -- SURVEY 8(a) P4;
+//   * _build_graph (algebra/lcs/lcs_graph.py:351-453): degenerate cases :370-377, sink :379-385,
+//     level loop with edge creation / node splitting / re-insertion :389-426, source :428-445,
+//     trimming of source and sink :447-451, supremal :453.
+// The graph builder works on integer node ids and flat arrays; nothing here touches symbols.
 #include "malcs_internal.hpp"
-extern "C" {
-int malcs_lcs_graph_batch(malcs_batch *, const int64_t *, const int64_t *, malcs_graphs **) { malcs_set_error("not implemented"); return MALCS_ERR_INTERNAL; }
-int malcs_graphs_destroy(malcs_graphs *) { return MALCS_OK; }
-int malcs_graphs_counts(const malcs_graphs *, int64_t *) { return MALCS_ERR_INTERNAL; }
-int malcs_graphs_status(const malcs_graphs *, int32_t *, int64_t *) { return MALCS_ERR_INTERNAL; }
-int malcs_graphs_supremal(const malcs_graphs *, int64_t *) { return MALCS_ERR_INTERNAL; }
-int malcs_graphs_runs(const malcs_graphs *, uint64_t, int64_t *) { return MALCS_ERR_INTERNAL; }
-int malcs_graphs_nodes(const malcs_graphs *, uint64_t, int64_t *) { return MALCS_ERR_INTERNAL; }
-int malcs_graphs_edges(const malcs_graphs *, uint64_t, int64_t *) { return MALCS_ERR_INTERNAL; }
-int malcs_graphs_timing(const malcs_graphs *, float *) { return MALCS_ERR_INTERNAL; }
+#include <algorithm>
+#include <atomic>
+#include <chrono>
+#include <cstring>
+#include <new>
+#include <thread>
+
+int malcs_graph_launch_forward(malcs_batch *b, int W, int logL, const uint32_t *d_work, uint32_t count,
+                               uint32_t *d_scratch, const uint64_t *d_sc_off, int32_t *d_dist);
+int malcs_graph_launch_reach(malcs_batch *b, int W, int logL, const uint32_t *d_work, uint32_t count,
+                             const uint32_t *d_scratch, const uint64_t *d_sc_off, const uint8_t *d_skip,
+                             void *d_events, const uint64_t *d_ev_off, const uint32_t *d_ev_cap, uint32_t *d_ev_cnt);
+int malcs_graph_launch_compact(malcs_ctx *ctx, const void *d_events, const uint64_t *d_ev_off, const uint32_t *d_ev_n,
+                               const uint64_t *d_out_off, uint32_t count, void *d_out);
+
+namespace {
+
+struct event { uint32_t row, col, level, kind; };      // kind 0 = run ends in (row, col); 1 = run starts in (row, col)
+
+struct run { int64_t row, col, len, level; };
+
+struct pair_graph {
+    int32_t status = MALCS_PAIR_OK;
+    int64_t distance = 0;
+    int64_t n_levels = 0;
+    int64_t supremal[4] = {0, 0, 0, 0};
+    std::vector<int64_t> runs;      // 4 per run (shifted row, col; length; level)
+    std::vector<int64_t> nodes;     // 3 per node
+    std::vector<int64_t> edges;     // 6 per edge
+};
+
+// ---- events -> runs in the reference's emission order -------------------------------------------
+bool runs_from_events(std::vector<event> &ev, int64_t m, int64_t n, std::vector<run> &out)
+{
+    // starts and ends alternate along every diagonal
+    std::sort(ev.begin(), ev.end(), [](const event &a, const event &b) {
+        const int64_t da = (int64_t)a.col - a.row, db = (int64_t)b.col - b.row;
+        if (da != db) return da < db;
+        if (a.row != b.row) return a.row < b.row;
+        return a.kind > b.kind;                      // a start sorts before the end of the same cell
+    });
+    if (ev.size() % 2) return false;
+    out.clear();
+    out.reserve(ev.size() / 2);
+    for (size_t i = 0; i < ev.size(); i += 2) {
+        const event &s = ev[i], &e = ev[i + 1];
+        if (s.kind != 1 || e.kind != 0) return false;
+        if ((int64_t)s.col - s.row != (int64_t)e.col - e.row || e.row < s.row) return false;
+        out.push_back({s.row, s.col, (int64_t)e.row - s.row + 1, e.level});
+    }
+    const int64_t delta = n - m, adelta = delta < 0 ? -delta : delta;
+    struct keyed { int64_t level, it, grp, dk, row; run r; };
+    std::vector<keyed> k;
+    k.reserve(out.size());
+    for (const run &r : out) {
+        const int64_t re = r.row + r.len, ce = r.col + r.len, diag = r.col - r.row;
+        const int64_t cost = re + ce - 2 * (r.level + 1);                    // forward edit cost of the corner after the run
+        const int64_t off = diag - delta, aoff = off < 0 ? -off : off;
+        const int64_t it = (cost + aoff - adelta) / 2;                       // sweep iteration that first affords it
+        const int64_t grp = diag < delta ? 0 : (diag > delta ? 1 : 2);
+        k.push_back({r.level, it, grp, grp == 0 ? diag : -diag, r.row, r});
+    }
+    std::sort(k.begin(), k.end(), [](const keyed &a, const keyed &b) {
+        if (a.level != b.level) return a.level < b.level;
+        if (a.it != b.it) return a.it < b.it;
+        if (a.grp != b.grp) return a.grp < b.grp;
+        if (a.dk != b.dk) return a.dk < b.dk;
+        return a.row < b.row;
+    });
+    for (size_t i = 0; i < k.size(); i++) out[i] = k[i].r;
+    return true;
 }
+
+// ---- _build_graph -------------------------------------------------------------------------------
+struct gedge { int32_t child; int64_t start, end, from, to; };
+
+struct builder {
+    // node arrays (Node.row/.col/.length/._length/._incoming, lcs_graph.py:36-44)
+    std::vector<int64_t> row, col, length, wlen, incoming;
+    std::vector<std::vector<gedge>> out;
+
+    int32_t add(int64_t r, int64_t c, int64_t l)
+    {
+        row.push_back(r); col.push_back(c); length.push_back(l); wlen.push_back(l); incoming.push_back(0);
+        out.emplace_back();
+        return (int32_t)row.size() - 1;
+    }
+};
+
+void build_graph(int64_t m, int64_t n, int64_t shift, const std::vector<run> &runs, int64_t n_levels, pair_graph &G)
+{
+    builder B;
+    int32_t source, sink;
+    const bool degenerate = runs.empty() || n_levels == 0;
+    if (degenerate) {                                                    // :370-377
+        source = B.add(shift, shift, 0);
+        if (m == 0 && n == 0) {
+            G.supremal[0] = G.supremal[1] = G.supremal[2] = G.supremal[3] = 0;
+        } else {
+            sink = B.add(m, n, 0);                                       // sink keeps unshifted coordinates
+            B.out[source].push_back({sink, shift, shift + m, 0, n});
+            G.supremal[0] = shift; G.supremal[1] = shift + m; G.supremal[2] = 0; G.supremal[3] = n;
+        }
+    } else {
+        std::vector<std::vector<int32_t>> levels((size_t)n_levels + 1);
+        for (const run &r : runs) levels[(size_t)r.level].push_back(B.add(r.row + shift, r.col + shift, r.len));
+
+        const int32_t last = levels[(size_t)n_levels - 1].back();        // :379-385
+        if (B.row[last] + B.length[last] == m + shift && B.col[last] + B.length[last] == n + shift) {
+            levels[(size_t)n_levels - 1].pop_back();
+            sink = B.add(B.row[last], B.col[last], B.length[last] + 1);
+        } else {
+            sink = B.add(m + shift, n + shift, 1);
+        }
+        levels[(size_t)n_levels].push_back(sink);
+
+        int64_t max_sink = 0;
+        for (int64_t depth = n_levels + 1; depth > 1; depth--) {         // depth == len_lcs_nodes, :389
+            std::vector<int32_t> &cur = levels[(size_t)depth - 1];
+            std::vector<int32_t> &below = levels[(size_t)depth - 2];
+            for (size_t qi = 0; qi < cur.size(); qi++) {                 // pop(0) in order, :390-391
+                const int32_t node = cur[qi];
+                if (node != sink && B.out[node].empty()) continue;       // :393-394
+                size_t idx_parent = 0;
+                for (size_t idx = 0; idx < below.size(); idx++) {        // :397
+                    const int32_t parent = below[idx];
+                    const int64_t pr = B.row[parent] + B.wlen[parent], pc = B.col[parent] + B.wlen[parent];
+                    const int64_t nr = B.row[node] + B.wlen[node], nc = B.col[node] + B.wlen[node];
+                    if (pr < nr && pc < nc) {                            // :398 strict dominance of the ends
+                        const gedge e{node, pr, nr - 1, pc - shift, nc - 1 - shift};    // :399-400
+                        if (node == sink) max_sink = std::max(max_sink, nr - 1);         // :402-403
+                        if (B.incoming[parent] == depth) {               // :405-412 split the parent
+                            const int32_t split = B.add(B.row[parent], B.col[parent], B.length[parent]);
+                            B.wlen[split] = B.wlen[parent];
+                            B.out[split] = B.out[parent];
+                            B.out[split].push_back(e);
+                            below[idx] = split;
+                            B.row[parent] += B.wlen[parent];
+                            B.col[parent] += B.wlen[parent];
+                            B.length[parent] -= B.wlen[parent];
+                        } else {
+                            B.out[parent].push_back(e);                  // :414
+                        }
+                        idx_parent = idx + 1;                            // :416
+                    }
+                }
+                if (B.wlen[node] > 1) {                                  // :418-423
+                    B.wlen[node] -= 1;
+                    if (idx_parent) B.incoming[node] = depth;
+                    below.insert(below.begin() + (std::ptrdiff_t)idx_parent, node);
+                }
+            }
+            std::vector<int32_t>().swap(cur);                            // :425
+        }
+
+        std::vector<int32_t> &l0 = levels[0];                            // :428-432
+        size_t first = 0;
+        source = l0[0];
+        if (B.row[source] == shift && B.col[source] == shift) first = 1;
+        else source = B.add(shift, shift, 0);
+        for (size_t qi = first; qi < l0.size(); qi++) {                  // :434-445
+            const int32_t node = l0[qi];
+            if (node != sink && B.out[node].empty()) continue;
+            const int64_t nr = B.row[node] + B.wlen[node], nc = B.col[node] + B.wlen[node];
+            if (B.row[source] < nr && B.col[source] < nc) {
+                if (node == sink) max_sink = std::max(max_sink, nr - 1);
+                B.out[source].push_back({node, B.row[source], nr - 1, B.col[source] - shift, nc - 1 - shift});
+            }
+        }
+        int64_t source_offset = shift;                                   // :447-451
+        if (!B.out[source].empty()) {
+            source_offset = B.out[source][0].start;
+            for (const gedge &e : B.out[source]) source_offset = std::min(source_offset, e.start);
+        }
+        source_offset -= shift;
+        B.row[source] += source_offset;
+        B.col[source] += source_offset;
+        B.length[source] -= source_offset;
+        B.length[sink] -= B.row[sink] + B.length[sink] - max_sink;
+        G.supremal[0] = B.row[source];                                   // :453
+        G.supremal[1] = B.row[sink] + B.length[sink];
+        G.supremal[2] = B.col[source] - shift;
+        G.supremal[3] = B.col[sink] + B.length[sink] - shift;
+    }
+
+    // canonical numbering: BFS by identity from the source, following edge order
+    std::vector<int32_t> id(B.row.size(), -1), order;
+    order.reserve(B.row.size());
+    id[source] = 0;
+    order.push_back(source);
+    size_t n_edges = 0;
+    for (size_t h = 0; h < order.size(); h++) {
+        for (const gedge &e : B.out[order[h]]) {
+            if (id[e.child] < 0) { id[e.child] = (int32_t)order.size(); order.push_back(e.child); }
+            n_edges++;
+        }
+    }
+    G.nodes.resize(order.size() * 3);
+    G.edges.resize(n_edges * 6);
+    size_t ei = 0;
+    for (size_t h = 0; h < order.size(); h++) {
+        const int32_t u = order[h];
+        G.nodes[3 * h] = B.row[u]; G.nodes[3 * h + 1] = B.col[u]; G.nodes[3 * h + 2] = B.length[u];
+        for (const gedge &e : B.out[u]) {
+            int64_t *o = &G.edges[6 * ei++];
+            o[0] = (int64_t)h; o[1] = id[e.child]; o[2] = e.start; o[3] = e.end; o[4] = e.from; o[5] = e.to;
+        }
+    }
+}
+
+struct launch_class { int W, logL; std::vector<uint32_t> pairs; };
+
+template <typename T> struct dev_buf {
+    T *p = nullptr;
+    ~dev_buf() { if (p) hipFree(p); }
+    int alloc(size_t n) { if (p) { hipFree(p); p = nullptr; } hipError_t e = hipMalloc(&p, (n ? n : 1) * sizeof(T)); return e == hipSuccess ? 0 : -1; }
+};
+
+uint32_t pow2ceil(uint32_t x) { uint32_t p = 1; while (p < x) p <<= 1; return p; }
+
+double now_ms()
+{
+    return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count();
+}
+
+}  // namespace
+
+struct malcs_graphs {
+    std::vector<pair_graph> g;
+    float timing[3] = {0, 0, 0};
+};
+
+static int graph_batch(malcs_batch *b, const int64_t *shift, const int64_t *max_distance, malcs_graphs *out)
+{
+    malcs_ctx *ctx = b->ctx;
+    hipStream_t st = ctx->stream;
+    const uint64_t N = b->n_pairs;
+    out->g.resize(N);
+    std::vector<std::vector<event>> pair_events(N);
+    std::vector<uint8_t> has_runs(N, 0);
+
+    // launch classes: the device needs 64*W*L >= m + 1 bits per pair (vertex rows 0..m)
+    std::vector<launch_class> classes;
+    for (uint64_t i = 0; i < N; i++) {
+        const uint32_t m = b->a_len[i], n = b->b_len[i];
+        pair_graph &G = out->g[i];
+        if (m == 0 || n == 0) {                       // no DP needed: LLCS = 0
+            G.distance = (int64_t)m + n;
+            continue;
+        }
+        const uint32_t words = m / 64u + 1u;
+        int W, logL = 0;
+        if (words <= 4) W = (int)pow2ceil(words);
+        else {
+            W = 4;
+            const uint32_t lanes = pow2ceil((words + 3u) / 4u);
+            if (lanes > 64u) {
+                malcs_set_error("pair %llu: reference window of %u symbols exceeds the %u the graph kernels hold",
+                                (unsigned long long)i, m, 64u * 4u * 64u - 1u);
+                return MALCS_ERR_TOO_LONG;
+            }
+            while ((1u << logL) < lanes) logL++;
+        }
+        size_t c = 0;
+        for (; c < classes.size(); c++) if (classes[c].W == W && classes[c].logL == logL) break;
+        if (c == classes.size()) classes.push_back({W, logL, {}});
+        classes[c].pairs.push_back((uint32_t)i);
+        has_runs[i] = 1;
+    }
+
+    size_t free_b = 0, total_b = 0;
+    MALCS_HIP(hipMemGetInfo(&free_b, &total_b));
+    const uint64_t budget_dwords = std::min<uint64_t>(free_b / 2, 64ull << 30) / 4;
+
+    float ms_fwd = 0, ms_reach = 0;
+    dev_buf<uint32_t> d_work, d_evcap, d_evcnt, d_scratch;
+    dev_buf<uint64_t> d_scoff, d_evoff, d_outoff;
+    dev_buf<uint8_t> d_skip;
+    dev_buf<event> d_events, d_packed;
+
+    for (const launch_class &lc : classes) {
+        const uint64_t NLtot = (uint64_t)(2 * lc.W) << lc.logL;
+        size_t pos = 0;
+        while (pos < lc.pairs.size()) {
+            // ---- chunk of pairs whose tie-bit rows fit the scratch budget ----
+            std::vector<uint32_t> work;
+            std::vector<uint64_t> sc_off;
+            uint64_t used = 0;
+            while (pos < lc.pairs.size()) {
+                const uint32_t pid = lc.pairs[pos];
+                const uint64_t need = ((uint64_t)b->b_len[pid] + 1ull) * 2ull * NLtot;
+                if (!work.empty() && used + need > budget_dwords) break;
+                if (need > budget_dwords) {
+                    malcs_set_error("pair %u needs %llu MiB of tie-bit rows; device has %llu MiB free", pid,
+                                    (unsigned long long)(need >> 18), (unsigned long long)(free_b >> 20));
+                    return MALCS_ERR_NOMEM;
+                }
+                work.push_back(pid); sc_off.push_back(used); used += need; pos++;
+            }
+            const uint32_t cnt = (uint32_t)work.size();
+            if (d_work.alloc(cnt) || d_scoff.alloc(cnt) || d_scratch.alloc(used) || d_skip.alloc(cnt) ||
+                d_evcap.alloc(cnt) || d_evcnt.alloc(cnt) || d_evoff.alloc(cnt) || d_outoff.alloc(cnt)) {
+                malcs_set_error("device allocation failed (chunk of %u pairs, %llu MiB of tie-bit rows)", cnt, (unsigned long long)(used >> 18));
+                return MALCS_ERR_NOMEM;
+            }
+            MALCS_HIP(hipMemcpyAsync(d_work.p, work.data(), cnt * 4ull, hipMemcpyHostToDevice, st));
+            MALCS_HIP(hipMemcpyAsync(d_scoff.p, sc_off.data(), cnt * 8ull, hipMemcpyHostToDevice, st));
+            MALCS_HIP(hipEventRecord(ctx->ev0, st));
+            int rc = malcs_graph_launch_forward(b, lc.W, lc.logL, d_work.p, cnt, d_scratch.p, d_scoff.p, b->d_dist);
+            if (rc) return rc;
+            MALCS_HIP(hipEventRecord(ctx->ev1, st));
+            // distances of the chunk (scattered in d_dist by pair id): fetch the whole array once per chunk
+            std::vector<int32_t> dist(N);
+            MALCS_HIP(hipMemcpyAsync(dist.data(), b->d_dist, N * 4ull, hipMemcpyDeviceToHost, st));
+            MALCS_HIP(hipStreamSynchronize(st));
+            float ms = 0;
+            MALCS_HIP(hipEventElapsedTime(&ms, ctx->ev0, ctx->ev1));
+            ms_fwd += ms;
+
+            std::vector<uint8_t> skip(cnt, 0);
+            std::vector<uint32_t> ev_cap(cnt);
+            std::vector<uint64_t> ev_off(cnt);
+            uint64_t ev_total = 0;
+            for (uint32_t s = 0; s < cnt; s++) {
+                const uint32_t pid = work[s];
+                pair_graph &G = out->g[pid];
+                G.distance = dist[pid];
+                const int64_t md = max_distance ? max_distance[pid] : 0;
+                if (md && G.distance > md) { skip[s] = 1; G.status = MALCS_PAIR_MAX_DISTANCE_EXCEEDED; }
+                ev_cap[s] = skip[s] ? 0u : 64u + 16u * (uint32_t)G.distance;
+                ev_off[s] = ev_total;
+                ev_total += ev_cap[s];
+            }
+            for (int attempt = 0;; attempt++) {
+                if (d_events.alloc(ev_total)) { malcs_set_error("device allocation failed (%llu events)", (unsigned long long)ev_total); return MALCS_ERR_NOMEM; }
+                MALCS_HIP(hipMemcpyAsync(d_skip.p, skip.data(), cnt, hipMemcpyHostToDevice, st));
+                MALCS_HIP(hipMemcpyAsync(d_evcap.p, ev_cap.data(), cnt * 4ull, hipMemcpyHostToDevice, st));
+                MALCS_HIP(hipMemcpyAsync(d_evoff.p, ev_off.data(), cnt * 8ull, hipMemcpyHostToDevice, st));
+                MALCS_HIP(hipMemsetAsync(d_evcnt.p, 0, cnt * 4ull, st));
+                MALCS_HIP(hipEventRecord(ctx->ev1, st));
+                rc = malcs_graph_launch_reach(b, lc.W, lc.logL, d_work.p, cnt, d_scratch.p, d_scoff.p, d_skip.p,
+                                              d_events.p, d_evoff.p, d_evcap.p, d_evcnt.p);
+                if (rc) return rc;
+                MALCS_HIP(hipEventRecord(ctx->ev2, st));
+                std::vector<uint32_t> ev_cnt(cnt);
+                MALCS_HIP(hipMemcpyAsync(ev_cnt.data(), d_evcnt.p, cnt * 4ull, hipMemcpyDeviceToHost, st));
+                MALCS_HIP(hipStreamSynchronize(st));
+                MALCS_HIP(hipEventElapsedTime(&ms, ctx->ev1, ctx->ev2));
+                ms_reach += ms;
+                bool overflow = false;
+                for (uint32_t s = 0; s < cnt; s++) if (ev_cnt[s] > ev_cap[s]) overflow = true;
+                if (overflow) {
+                    if (attempt) { malcs_set_error("event buffer overflow persisted after a resize"); return MALCS_ERR_INTERNAL; }
+                    ev_total = 0;                      // the counts are exact: size every region to its count and redo the pass
+                    for (uint32_t s = 0; s < cnt; s++) { ev_cap[s] = std::max(ev_cap[s], ev_cnt[s]); ev_off[s] = ev_total; ev_total += ev_cap[s]; }
+                    continue;
+                }
+                // gather the used parts and bring them home
+                std::vector<uint64_t> out_off(cnt);
+                uint64_t packed = 0;
+                for (uint32_t s = 0; s < cnt; s++) { out_off[s] = packed; packed += ev_cnt[s]; }
+                if (d_packed.alloc(packed)) { malcs_set_error("device allocation failed (%llu packed events)", (unsigned long long)packed); return MALCS_ERR_NOMEM; }
+                MALCS_HIP(hipMemcpyAsync(d_outoff.p, out_off.data(), cnt * 8ull, hipMemcpyHostToDevice, st));
+                rc = malcs_graph_launch_compact(ctx, d_events.p, d_evoff.p, d_evcnt.p, d_outoff.p, cnt, d_packed.p);
+                if (rc) return rc;
+                std::vector<event> host_ev(packed);
+                if (packed) MALCS_HIP(hipMemcpyAsync(host_ev.data(), d_packed.p, packed * sizeof(event), hipMemcpyDeviceToHost, st));
+                MALCS_HIP(hipStreamSynchronize(st));
+                for (uint32_t s = 0; s < cnt; s++)
+                    pair_events[work[s]].assign(host_ev.begin() + (std::ptrdiff_t)out_off[s],
+                                                host_ev.begin() + (std::ptrdiff_t)(out_off[s] + ev_cnt[s]));
+                break;
+            }
+        }
+    }
+    out->timing[0] = ms_fwd;
+    out->timing[1] = ms_reach;
+
+    // ---- host: runs, ordering, graph compression (threads over pairs) ----
+    const double t0 = now_ms();
+    std::atomic<uint64_t> next(0);
+    std::atomic<int> failed(0);
+    auto worker = [&]() {
+        std::vector<run> runs;
+        for (;;) {
+            const uint64_t i = next.fetch_add(1);
+            if (i >= N) break;
+            pair_graph &G = out->g[i];
+            if (G.status != MALCS_PAIR_OK) continue;
+            const int64_t m = b->a_len[i], n = b->b_len[i];
+            runs.clear();
+            if (has_runs[i] && !runs_from_events(pair_events[i], m, n, runs)) { failed.store(1); continue; }
+            const int64_t llcs = (m + n - G.distance) / 2;
+            G.n_levels = runs.empty() ? (std::min(m, n) > 0 ? 1 : 0) : llcs;
+            const int64_t sh = shift ? shift[i] : 0;
+            G.runs.resize(runs.size() * 4);
+            for (size_t r = 0; r < runs.size(); r++) {
+                G.runs[4 * r] = runs[r].row + sh; G.runs[4 * r + 1] = runs[r].col + sh;
+                G.runs[4 * r + 2] = runs[r].len; G.runs[4 * r + 3] = runs[r].level;
+                if (runs[r].level < 0 || runs[r].level >= llcs) failed.store(1);
+            }
+            if (failed.load()) continue;
+            build_graph(m, n, sh, runs, runs.empty() ? 0 : llcs, G);
+        }
+    };
+    unsigned nt = std::min<unsigned>(16u, std::max(1u, std::thread::hardware_concurrency()));
+    if (N < 64) nt = 1;
+    std::vector<std::thread> pool;
+    for (unsigned t = 1; t < nt; t++) pool.emplace_back(worker);
+    worker();
+    for (std::thread &t : pool) t.join();
+    out->timing[2] = (float)(now_ms() - t0);
+    if (failed.load()) { malcs_set_error("device events do not form runs (internal error)"); return MALCS_ERR_INTERNAL; }
+    return MALCS_OK;
+}
+
+extern "C" {
+
+int malcs_lcs_graph_batch(malcs_batch *b, const int64_t *shift, const int64_t *max_distance, malcs_graphs **graphs)
+{
+    if (!graphs) { malcs_set_error("graphs is NULL"); return MALCS_ERR_ARG; }
+    *graphs = nullptr;
+    if (!b) { malcs_set_error("batch is NULL"); return MALCS_ERR_ARG; }
+    MALCS_HIP(hipSetDevice(b->ctx->device));
+    malcs_graphs *g = new (std::nothrow) malcs_graphs();
+    if (!g) { malcs_set_error("out of host memory"); return MALCS_ERR_NOMEM; }
+    int rc;
+    try {
+        rc = graph_batch(b, shift, max_distance, g);
+    } catch (const std::bad_alloc &) {
+        malcs_set_error("out of host memory");
+        rc = MALCS_ERR_NOMEM;
+    }
+    if (rc) { delete g; return rc; }
+    *graphs = g;
+    return MALCS_OK;
+}
+
+int malcs_graphs_destroy(malcs_graphs *g) { delete g; return MALCS_OK; }
+
+int malcs_graphs_counts(const malcs_graphs *g, int64_t *counts)
+{
+    if (!g || !counts) { malcs_set_error("NULL argument"); return MALCS_ERR_ARG; }
+    for (size_t i = 0; i < g->g.size(); i++) {
+        counts[4 * i] = (int64_t)g->g[i].runs.size() / 4;
+        counts[4 * i + 1] = g->g[i].n_levels;
+        counts[4 * i + 2] = (int64_t)g->g[i].nodes.size() / 3;
+        counts[4 * i + 3] = (int64_t)g->g[i].edges.size() / 6;
+    }
+    return MALCS_OK;
+}
+
+int malcs_graphs_status(const malcs_graphs *g, int32_t *status, int64_t *distance)
+{
+    if (!g) { malcs_set_error("NULL argument"); return MALCS_ERR_ARG; }
+    for (size_t i = 0; i < g->g.size(); i++) {
+        if (status) status[i] = g->g[i].status;
+        if (distance) distance[i] = g->g[i].distance;
+    }
+    return MALCS_OK;
+}
+
+int malcs_graphs_supremal(const malcs_graphs *g, int64_t *supremal4)
+{
+    if (!g || !supremal4) { malcs_set_error("NULL argument"); return MALCS_ERR_ARG; }
+    for (size_t i = 0; i < g->g.size(); i++) memcpy(supremal4 + 4 * i, g->g[i].supremal, sizeof(int64_t) * 4);
+    return MALCS_OK;
+}
+
+#define MALCS_COPY_OUT(field)                                                                        \
+    if (!g || i >= g->g.size() || (!dst && !g->g[i].field.empty())) { malcs_set_error("bad argument"); return MALCS_ERR_ARG; } \
+    if (!g->g[i].field.empty()) memcpy(dst, g->g[i].field.data(), g->g[i].field.size() * sizeof(int64_t)); \
+    return MALCS_OK;
+
+int malcs_graphs_runs(const malcs_graphs *g, uint64_t i, int64_t *dst) { MALCS_COPY_OUT(runs) }
+int malcs_graphs_nodes(const malcs_graphs *g, uint64_t i, int64_t *dst) { MALCS_COPY_OUT(nodes) }
+int malcs_graphs_edges(const malcs_graphs *g, uint64_t i, int64_t *dst) { MALCS_COPY_OUT(edges) }
+
+int malcs_graphs_timing(const malcs_graphs *g, float *out3)
+{
+    if (!g || !out3) { malcs_set_error("NULL argument"); return MALCS_ERR_ARG; }
+    memcpy(out3, g->timing, sizeof(g->timing));
+    return MALCS_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,273 @@
+"""LCS graphs (all minimal alignments) built on the GPU.
+
+Drop-in for the reference's `algebra/lcs/lcs_graph.py`: same class, attributes, constructors,
+traversals and exceptions.  `LCSgraph.__init__` (= `_lcs_nodes` + `_build_graph`, reference
+:59-61) runs in libmalcs: kernel family 2 finds the optimal match runs, the library's host half
+compresses them; this module only materialises `Node`/`Variant` objects from the arrays.
+
+`LCSgraph.batch` builds many graphs in one device batch; the single-pair constructor is a batch
+of one.
+"""
+
+from collections import deque
+
+import numpy as np
+
+from .. import _native
+from ..variants import Variant, patch
+from .encoding import encode_pairs
+
+
+class LCSgraph:
+    """LCS graph class for storing all minimal alignments.
+
+    Attributes
+    ----------
+    distance : int
+        The simple edit distance.
+    supremal : `Variant`
+        The supremal variant representation.
+    """
+
+    class Node:
+        """A stretch of matching symbols (reference lcs_graph.py:34-57)."""
+
+        __slots__ = ("row", "col", "length", "edges")
+
+        def __init__(self, row, col, length):
+            self.row = row
+            self.col = col
+            self.length = length
+            self.edges = []
+
+        def __eq__(self, other):
+            return (self.row, self.col, self.length) == (other.row, other.col, other.length)
+
+        def __hash__(self):
+            return hash((self.row, self.col, self.length))
+
+        def __lt__(self, other):
+            return (self.row, self.col) < (other.row, other.col)
+
+        def __repr__(self):
+            return f"{self.row, self.col, self.length}"
+
+    def __init__(self, reference, observed, shift=0, max_distance=None):
+        built = LCSgraph.batch([(reference, observed)], [shift], [max_distance])[0]
+        self.distance = built.distance
+        self.supremal = built.supremal
+        self._source = built._source
+
+    @classmethod
+    def _from_arrays(cls, observed, distance, supremal, nodes, edges):
+        self = cls.__new__(cls)
+        self.distance = int(distance)
+        start, end, lo, hi = (int(x) for x in supremal)
+        self.supremal = Variant(start, end, observed[lo:hi])
+        made = [cls.Node(int(r), int(c), int(length)) for r, c, length in nodes.tolist()]
+        for src, dst, v_start, v_end, v_lo, v_hi in edges.tolist():
+            made[src].edges.append((made[dst], Variant(v_start, v_end, observed[v_lo:v_hi])))
+        self._source = made[0]
+        return self
+
+    @classmethod
+    def batch(cls, pairs, shifts=None, max_distances=None, ctx=None):
+        """`[LCSgraph(reference, observed, shift, max_distance), ...]` in one device batch.
+
+        Raises ValueError("maximum distance exceeded") if any pair exceeds its limit
+        (reference lcs_graph.py:345-346)."""
+        pairs = list(pairs)
+        n = len(pairs)
+        if n == 0:
+            return []
+        ctx = ctx or _native.default_context()
+        syms, a_off, a_len, b_off, b_len, n_symbols = encode_pairs(pairs)
+        shift = np.zeros(n, dtype=np.int64) if shifts is None else np.asarray(list(shifts), dtype=np.int64)
+        limit = None
+        if max_distances is not None:
+            limit = np.array([int(x) if x else 0 for x in max_distances], dtype=np.int64)
+        batch = _native.Batch(ctx, syms, a_off, a_len, b_off, b_len, n_symbols)
+        try:
+            res = batch.graphs(shift, limit)
+        finally:
+            batch.close()
+        try:
+            if np.any(res.status == _native.PAIR_MAX_DISTANCE_EXCEEDED):
+                raise ValueError("maximum distance exceeded")
+            return [cls._from_arrays(pairs[i][1], res.distance[i], res.supremal[i], res.nodes(i), res.edges(i))
+                    for i in range(n)]
+        finally:
+            res.close()
+
+    @classmethod
+    def from_sequence(cls, reference, observed):
+        """The supremal LCS graph for two sequences (reference lcs_graph.py:63-70)."""
+        if reference == observed:
+            return cls("", "")
+        prefix_len, suffix_len = trim(reference, observed)
+        delins = Variant(prefix_len, len(reference) - suffix_len, observed[prefix_len:len(observed) - suffix_len])
+        return cls.from_variant(reference, [delins])
+
+    @classmethod
+    def from_supremal(cls, reference, supremal):
+        """The supremal LCS graph for a supremal variant (reference lcs_graph.py:72-75)."""
+        return cls(reference[supremal.start:supremal.end], supremal.sequence, shift=supremal.start)
+
+    @classmethod
+    def from_variant(cls, reference, variants, offset=10):
+        """Iteratively find the supremal LCS graph for an allele by repeatedly widening a
+        range of influence (reference lcs_graph.py:77-123).
+
+        Parameters
+        ----------
+        reference : str
+            The reference sequence.
+        variants : list of `Variant`s
+            The allele of interest.
+        offset : int, optional
+            The minimum offset around the variants.
+        """
+        if not variants:
+            return cls("", "")
+        start = min(v.start for v in variants)
+        end = max(v.end for v in variants)
+        observed = patch(reference[start:end], [Variant(v.start - start, v.end - start, v.sequence) for v in variants])
+        if reference[start:end] == observed:
+            return cls("", "")
+        allele = Variant(start, end, observed)
+        offset = max(offset, len(allele) // 2, 1)
+        while True:
+            lo = max(0, allele.start - offset)
+            hi = min(len(reference), allele.end + offset)
+            window = reference[lo:allele.start] + allele.sequence + reference[allele.end:hi]
+            graph = cls(reference[lo:hi], window, shift=lo)
+            inside_left = graph.supremal.start > lo or graph.supremal.start == 0
+            inside_right = graph.supremal.end < hi or graph.supremal.end == len(reference)
+            if inside_left and inside_right:
+                return graph
+            offset *= 2
+
+    def bfs_traversal(self, atomics=False):
+        """Generate all (source node, sink node, [variants]) edges in BFS order
+        (reference lcs_graph.py:125-160; nodes compare by value, as there)."""
+        seen = set()
+        todo = deque([self._source])
+        while todo:
+            node = todo.popleft()
+            if node in seen:
+                continue
+            for child, variant in node.edges:
+                if atomics:
+                    for atomic in variant.atomics():
+                        yield node, child, atomic
+                else:
+                    yield node, child, [variant]
+                todo.append(child)
+            seen.add(node)
+
+    def edges(self):
+        """Set of all edges in the LCS graph (reference lcs_graph.py:162-164)."""
+        return {variants[0] for _, _, variants in self.bfs_traversal()}
+
+    def nodes(self):
+        """Generate all nodes in the LCS graph (reference lcs_graph.py:166-177)."""
+        seen = {self._source}
+        stack = [self._source]
+        while stack:
+            node = stack.pop()
+            yield node
+            for child, _ in node.edges:
+                if child not in seen:
+                    seen.add(child)
+                    stack.append(child)
+
+    def paths(self, atomics=False):
+        """Traverse all paths (alignments) in the LCS graph (reference lcs_graph.py:179-205)."""
+        def walk(node, path):
+            if not node.edges:
+                yield path
+            for child, variant in node.edges:
+                if atomics:
+                    for atomic in variant.atomics():
+                        yield from walk(child, path + atomic)
+                else:
+                    yield from walk(child, path + [variant])
+
+        return walk(self._source, [])
+
+    def uniq_atomics(self):
+        """The set of unique atomics for the whole LCS graph (reference lcs_graph.py:207-217)."""
+        found = set()
+        for _, _, variants in self.bfs_traversal():
+            variant = variants[0]
+            symbols = set(variant.sequence)
+            for idx in range(variant.start, variant.end):
+                found.add((idx, ""))
+                found.update((idx, ch) for ch in symbols)
+            found.update((variant.end, ch) for ch in symbols)
+        return found
+
+    def overlap(self, other):
+        """Common and all unique atomics of two LCS graphs (reference lcs_graph.py:219-224)."""
+        lhs = self.uniq_atomics()
+        rhs = other.uniq_atomics()
+        return lhs & rhs, lhs | rhs
+
+    def is_disjoint(self, other):
+        """Are two LCS graphs disjoint (reference lcs_graph.py:226-228)."""
+        return self.uniq_atomics().isdisjoint(other.uniq_atomics())
+
+
+def trim(lhs, rhs):
+    """Lengths of the common prefix and of the common suffix of what remains
+    (reference lcs_graph.py:231-235)."""
+    limit = min(len(lhs), len(rhs))
+    prefix = _common_prefix(lhs, rhs, limit)
+    rest = limit - prefix
+    suffix = _common_prefix(lhs[::-1], rhs[::-1], rest) if rest else 0
+    return prefix, suffix
+
+
+def _common_prefix(lhs, rhs, limit):
+    """Number of leading positions (at most `limit`) where the two strings agree."""
+    step = 1 << 16
+    done = 0
+    while done < limit:
+        hi = min(limit, done + step)
+        if lhs[done:hi] == rhs[done:hi]:
+            done = hi
+            continue
+        lo_bad, hi_bad = done, hi          # first difference lies in [lo_bad, hi_bad)
+        while hi_bad - lo_bad > 1:
+            mid = (lo_bad + hi_bad) // 2
+            if lhs[lo_bad:mid] == rhs[lo_bad:mid]:
+                lo_bad = mid
+            else:
+                hi_bad = mid
+        return lo_bad
+    return done
+
+
+def _lcs_nodes(reference, observed, shift=0, max_distance=None):
+    """Distance and level-bucketed match runs (reference lcs_graph.py:238-348).
+
+    The device returns the runs that lie on some minimal alignment, in the reference's order;
+    the reference additionally lists runs its sweep walked over that `_build_graph` then discards
+    (SURVEY 8(a) P3), so the lists here are the sub-lists of the reference's that matter.
+    """
+    ctx = _native.default_context()
+    syms, a_off, a_len, b_off, b_len, n_symbols = encode_pairs([(reference, observed)])
+    batch = _native.Batch(ctx, syms, a_off, a_len, b_off, b_len, n_symbols)
+    try:
+        res = batch.graphs(np.array([shift], dtype=np.int64), np.array([int(max_distance or 0)], dtype=np.int64))
+    finally:
+        batch.close()
+    try:
+        if res.status[0] == _native.PAIR_MAX_DISTANCE_EXCEEDED:
+            raise ValueError("maximum distance exceeded")
+        levels = [[] for _ in range(int(res.counts[0, 1]))]
+        for row, col, length, level in res.runs(0).tolist():
+            levels[level].append(LCSgraph.Node(row, col, length))
+        return int(res.distance[0]), levels
+    finally:
+        res.close()
