@@ -1,0 +1,272 @@
+"""GPU parity tests: the HIP path (through the C-ABI and the algebra.lcs-shaped facade) against the
+golden fixtures captured from the reference and against the CPU oracle on seeded inputs."""
+
+import numpy as np
+import pytest
+
+from conftest import load_golden
+from util import assert_graph, digest, graph_record, graph_record_from_arrays, observables
+import gen
+
+pytestmark = pytest.mark.gpu
+
+REF = load_golden("reference_tests.json")
+SMALL = load_golden("random_small.json")
+MEDIUM = load_golden("random_medium.json")
+SEQS = load_golden("random_sequences.json")
+LARGE = load_golden("large.json")
+
+
+@pytest.fixture(scope="module")
+def native():
+    from algebra_amd import _native
+    assert _native.default_context().device_info()[1] > 0      # the HIP library is the one doing the work
+    return _native
+
+
+# ---------------------------------------------------------------------------------------------
+# family 1: distances
+# ---------------------------------------------------------------------------------------------
+
+def test_edit_distance_reference_vectors(native):
+    import algebra_amd
+    # the reference's own three vectors, as its test reads (tests/lcs/test_edit_distance.py:5-11)
+    assert algebra_amd.edit_distance("CTCGGCATTA", "GGCTGGCTGT") == 6
+    assert algebra_amd.edit_distance("TTT", "TTTTAT") == 3
+    assert algebra_amd.edit_distance("TTTTAT", "TTT") == 3
+    cases = REF["lcs"] + SMALL["lcs"] + MEDIUM["lcs"]
+    got = algebra_amd.edit_distance_batch([(c["reference"], c["observed"]) for c in cases])
+    assert got.tolist() == [c["edit_distance"] for c in cases]
+    swapped = algebra_amd.edit_distance_batch([(c["observed"], c["reference"]) for c in cases])
+    assert swapped.tolist() == got.tolist()
+
+
+@pytest.mark.parametrize("n_symbols", [1, 2, 4, 5, 8, 9, 16, 17, 200])
+def test_edit_distance_vs_oracle_word_boundaries(native, n_symbols):
+    from oracle import oracle as O
+    rs = np.random.RandomState(100 + n_symbols)
+    lengths = [0, 1, 31, 32, 33, 63, 64, 65, 127, 128, 129, 191, 192, 193, 255, 256, 257, 300, 511, 512, 513,
+               1000, 1023, 1024, 1025, 2047, 2048, 2049, 4095, 4096, 4097]
+    seqs = []
+    for m in lengths:
+        a = rs.randint(0, n_symbols, m).astype(np.uint8)
+        keep = rs.random_sample(m) > 0.02
+        b = np.concatenate([a[keep], rs.randint(0, n_symbols, rs.randint(0, 4)).astype(np.uint8)])
+        seqs.append((a, b))
+        seqs.append((a, rs.randint(0, n_symbols, max(0, m + rs.randint(-2, 3))).astype(np.uint8)))
+    flat = [x for ab in seqs for x in ab]
+    off = np.concatenate([[0], np.cumsum([len(x) for x in flat])]).astype(np.uint64)
+    lens = np.array([len(x) for x in flat], np.uint32)
+    syms = np.concatenate(flat + [np.zeros(1, np.uint8)])
+    args = (syms, off[0:-1:2], lens[0::2], off[1::2], lens[1::2])
+    batch = native.Batch(native.default_context(), *args, n_symbols=max(n_symbols, 1))
+    got = batch.distances()
+    batch.close()
+    assert got.tolist() == O.edit_distance_batch(*args).tolist()
+
+
+def test_edit_distance_long_patterns(native):
+    from oracle import oracle as O
+    rs = np.random.RandomState(5)
+    pairs = []
+    for m in (10000, 16383, 16384, 16385, 40000, 65536):
+        a = gen.random_seq(rs, m)
+        pairs.append((a, gen.mutate(rs, a, 0.003, 0.003)))
+    import algebra_amd
+    got = algebra_amd.edit_distance_batch(pairs)
+    assert got.tolist() == [O.edit_distance(a, b) for a, b in pairs]
+
+
+def test_edit_distance_c2_full_size(native):
+    """BASELINE config 2 at full size: 100k pairs of 1 kb windows, ~2% indels."""
+    from oracle import oracle as O
+    n = 100000
+    syms, a_off, a_len, b_off, b_len = gen.c2_batch(n)
+    ctx = native.default_context()
+    batch = native.Batch(ctx, syms, a_off, a_len, b_off, b_len, 4)
+    d = batch.distances()
+    batch.close()
+    # size-independent properties of the indel distance
+    m, k = a_len.astype(np.int64), b_len.astype(np.int64)
+    assert np.all(d >= np.abs(m - k)) and np.all(d <= m + k)
+    assert np.all((d - (m + k)) % 2 == 0)
+    # symmetry: the same batch with the roles swapped
+    swapped = native.Batch(ctx, syms, b_off, b_len, a_off, a_len, 4)
+    assert np.array_equal(swapped.distances(), d)
+    swapped.close()
+    # identical pairs give 0
+    same = native.Batch(ctx, syms, a_off[:1000], a_len[:1000], a_off[:1000], a_len[:1000], 4)
+    assert not same.distances().any()
+    same.close()
+    # a seeded sample against the oracle
+    pick = np.random.RandomState(0).choice(n, 3000, replace=False)
+    ref = O.edit_distance_batch(syms, a_off[pick], a_len[pick], b_off[pick], b_len[pick])
+    assert np.array_equal(d[pick], ref)
+    assert 15 < d.mean() < 25
+
+
+def test_empty_batch_and_bad_arguments(native):
+    import algebra_amd
+    assert algebra_amd.edit_distance_batch([]).tolist() == []
+    assert algebra_amd.edit_distance("", "") == 0
+    assert algebra_amd.edit_distance("", "ACGT") == 4
+    ctx = native.default_context()
+    with pytest.raises(native.MalcsError):
+        native.Batch(ctx, np.zeros(4, np.uint8), [0], [10], [0], [2], 4)     # sequence outside the buffer
+    with pytest.raises(native.MalcsError):
+        native.Batch(ctx, np.zeros(4, np.uint8), [0], [2], [0], [2], 0)      # n_symbols out of range
+
+
+# ---------------------------------------------------------------------------------------------
+# family 2: graphs
+# ---------------------------------------------------------------------------------------------
+
+def build(cases):
+    from algebra_amd.lcs import LCSgraph
+    return LCSgraph.batch([(c["reference"], c["observed"]) for c in cases], [c["shift"] for c in cases])
+
+
+def test_graph_reference_vectors(native):
+    graphs = build(REF["lcs"])
+    for rec, graph in zip(REF["lcs"], graphs):
+        assert_graph(rec, graph_record(graph))
+        obs = observables(graph)
+        if "observables" in rec:
+            assert obs == rec["observables"], (rec["reference"], rec["observed"])
+        else:
+            assert {k: digest(v) for k, v in obs.items()} == rec["observables_sha256"]
+
+
+def test_graph_like_the_reference_tests(native):
+    """A few vectors written the way tests/lcs/test_lcs_graph.py writes them."""
+    from algebra_amd.lcs import LCSgraph
+    from algebra_amd.variants import Variant
+    assert LCSgraph("", "").edges() == set()
+    assert LCSgraph("A", "A").edges() == set()
+    assert LCSgraph("TCTC", "TC").edges() == {Variant(0, 2, ""), Variant(1, 3, ""), Variant(2, 4, "")}
+    assert list(LCSgraph("AAAA", "AAA").nodes()) == [LCSgraph.Node(0, 0, 3), LCSgraph.Node(1, 0, 3)]
+    assert list(LCSgraph("GACTACGAGACAC", "TACGAGACAC").nodes()) == [LCSgraph.Node(0, 0, 0), LCSgraph.Node(3, 0, 0)]
+    graph = LCSgraph("TTGGTT", "AAGTTAG")
+    assert [e for *_, e in graph.bfs_traversal()] == [
+        [Variant(0, 0, "AAG")], [Variant(0, 2, "AA")], [Variant(0, 3, "AA")], [Variant(2, 2, "A")],
+        [Variant(2, 3, "A")], [Variant(3, 4, "")], [Variant(6, 6, "AG")], [Variant(3, 6, "")], [Variant(4, 6, "")]]
+    assert list(LCSgraph("TTT", "TATTTT").paths())[:3] == [
+        [Variant(1, 1, "A"), Variant(3, 3, "TT")],
+        [Variant(1, 1, "A"), Variant(2, 2, "T"), Variant(3, 3, "T")],
+        [Variant(1, 1, "A"), Variant(2, 2, "TT")]]
+    assert list(LCSgraph("", "").paths()) == [[]]
+    assert str(LCSgraph.Node(0, 0, 0)) == "(0, 0, 0)"
+
+
+def test_graph_random_small(native):
+    graphs = build(SMALL["lcs"])
+    for rec, graph in zip(SMALL["lcs"], graphs):
+        assert_graph(rec, graph_record(graph))
+
+
+def test_graph_random_medium(native):
+    graphs = build(MEDIUM["lcs"])
+    for rec, graph in zip(MEDIUM["lcs"], graphs):
+        got = graph_record(graph)
+        assert got["distance"] == rec["distance"] and got["supremal"] == rec["supremal"], rec["name"]
+        assert len(got["nodes"]) == rec["n_nodes"] and len(got["edges"]) == rec["n_edges"], rec["name"]
+        assert digest(got) == rec["graph_sha256"], rec["name"]
+
+
+def test_graph_arrays_vs_oracle(native):
+    """Straight through the C-ABI (no facade objects): arrays equal the oracle's, runs are a
+    sub-list of the oracle's level lists."""
+    from oracle import oracle as O
+    from algebra_amd.lcs.encoding import encode_pairs
+    rs = np.random.RandomState(77)
+    pairs, shifts = [], []
+    for _ in range(300):
+        kind = ["random", "indel", "sparse", "tandem"][rs.randint(0, 4)]
+        a, b = gen.pair_of_kind(rs, kind, int(rs.randint(1, 400)), "ACGT"[:rs.randint(1, 5)])
+        pairs.append((a, b))
+        shifts.append(int(rs.randint(0, 50)))
+    syms, a_off, a_len, b_off, b_len, n_symbols = encode_pairs(pairs)
+    batch = native.Batch(native.default_context(), syms, a_off, a_len, b_off, b_len, n_symbols)
+    res = batch.graphs(np.array(shifts, np.int64))
+    batch.close()
+    for i, (a, b) in enumerate(pairs):
+        ref = O.lcs_graph(a, b, shifts[i])
+        assert res.distance[i] == ref.distance
+        assert tuple(res.supremal[i]) == ref.supremal
+        assert np.array_equal(res.nodes(i), ref.nodes) and np.array_equal(res.edges(i), ref.edges)
+        mine = [tuple(r) for r in res.runs(i).tolist()]
+        theirs = [tuple(r) for r in ref.runs[np.argsort(ref.runs[:, 3], kind="stable")].tolist()]
+        it = iter(theirs)
+        assert all(r in it for r in mine), (a, b)          # ordered sub-list
+    res.close()
+
+
+def test_lcs_nodes_facade(native):
+    from algebra_amd.lcs.lcs_graph import _lcs_nodes
+    for a, b in (("AA", "ACA"), ("ACA", "AA"), ("CTCGGCATTA", "GGCTGGCTGT"), ("TTT", "TTTTAT"), ("", "")):
+        rec = next(r for r in REF["lcs"] if r["reference"] == a and r["observed"] == b and r["shift"] == 0)
+        distance, levels = _lcs_nodes(a, b)
+        assert distance == rec["graph"]["distance"]
+        assert distance == len(a) - len(levels) + len(b) - len(levels)      # reference test :50
+        for got, want in zip(levels, rec["levels"]):
+            it = iter(want)
+            assert all([n.row, n.col, n.length] in it for n in got)
+
+
+def test_max_distance(native):
+    from algebra_amd.lcs import LCSgraph
+    from algebra_amd.lcs.lcs_graph import _lcs_nodes
+    for rec in REF["max_distance"] + SMALL["max_distance"]:
+        a, b, md = rec["reference"], rec["observed"], rec["max_distance"]
+        if "error" in rec:
+            with pytest.raises(ValueError) as exc:
+                _lcs_nodes(a, b, max_distance=md)
+            assert str(exc.value) == rec["error"]
+            with pytest.raises(ValueError):
+                LCSgraph(a, b, max_distance=md)
+        else:
+            assert _lcs_nodes(a, b, max_distance=md)[0] == rec["distance"]
+            assert LCSgraph(a, b, max_distance=md).distance == rec["distance"]
+
+
+def test_from_sequence(native):
+    from algebra_amd.lcs import LCSgraph
+    for rec in REF["sequences"] + SEQS["sequences"]:
+        graph = LCSgraph.from_sequence(rec["reference"], rec["observed"])
+        assert_graph(rec, graph_record(graph))
+        if "observables" in rec:
+            assert observables(graph) == rec["observables"]
+
+
+def test_from_variant_and_from_supremal(native):
+    from algebra_amd.lcs import LCSgraph
+    from algebra_amd.variants import Variant
+    for rec in REF["from_variant"]:
+        variants = [Variant(*v) for v in rec["variants"]]
+        graph = LCSgraph.from_variant(rec["reference"], variants, rec["offset"])
+        assert graph_record(graph) == rec["graph"]
+    for rec in REF["from_supremal"]:
+        graph = LCSgraph.from_supremal(rec["reference"], Variant(*rec["supremal"]))
+        assert graph_record(graph) == rec["graph"]
+
+
+@pytest.mark.parametrize("idx", [i for i, r in enumerate(LARGE["from_sequence"]) if r["len_reference"] <= 16000])
+def test_large_from_sequence(native, idx):
+    """BASELINE config 3 shape: 10 kb windows, full graph, hash of the canonical record."""
+    from algebra_amd.lcs import LCSgraph
+    rec = LARGE["from_sequence"][idx]
+    a, b = gen.large_pair(rec["case"])
+    assert digest([a, b]) == rec["input_sha256"]
+    graph = LCSgraph.from_sequence(a, b)
+    got = graph_record(graph)
+    assert got["distance"] == rec["distance"]
+    assert [got["supremal"][0], got["supremal"][1]] == rec["supremal_pos"]
+    assert len(got["nodes"]) == rec["n_nodes"] and len(got["edges"]) == rec["n_edges"]
+    assert digest(got) == rec["graph_sha256"]
+
+
+def test_graph_size_limit_is_loud(native):
+    from algebra_amd.lcs import LCSgraph
+    a = "ACGT" * 5000
+    with pytest.raises(native.MalcsError, match="exceeds"):
+        LCSgraph(a, a[:-1])
