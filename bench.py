@@ -1,0 +1,191 @@
+#!/usr/bin/env python3
+"""bench.py -- BASELINE config 2: batched LCS edit distance over 1 kb windows on MI355X.
+
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--pairs P]
+
+One "step" is one pass of kernel family 1 over a batch of P = 100 000 pairs of ~1 kb windows with
+~2 % indels, the packed bit-plane arena already resident in HBM.  With N > 1 the
+driver starts one rank per GPU (torch.distributed.run); every rank owns its own batch of P pairs
+(independent pairs, no data-path collective => weak scaling) and the job rate is all pairs of
+all ranks over the slowest rank's time.
+
+Prints ONE JSON line (rank 0).  `value` is whole-job GCUPS = sum(m_i * n_i) / seconds / 1e9
+(unpadded full-matrix-equivalent cells); pairs/s is printed beside it.
+`roofline` is for the dominant kernel (k_llcs_bitpar), timed with HIP events on the library's
+stream; `cpu_baseline` times the CPU oracle (port of the reference's O(NP) algorithm) on the host.
+"""
+
+import argparse
+import json
+import multiprocessing
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+
+import numpy as np  # noqa: E402
+
+PEAK_LANE_OPS = 256 * 4 * 32 * 2.4e9          # 256 CU x 4 SIMD x 32 lanes/clk x 2.4 GHz = 78.6 T int32 lane-ops/s
+OPS_PER_CELL = 0.125                           # 4 dword ops per 32 cells
+
+
+_DATA = None        # the batch, inherited by the forked CPU-baseline workers (no pickling of 200 MB)
+
+
+def _oracle_pass(bounds):
+    from oracle import oracle as O
+    syms, a_off, a_len, b_off, b_len = _DATA
+    lo, hi = bounds
+    O.edit_distance_batch(syms, a_off[lo:hi], a_len[lo:hi], b_off[lo:hi], b_len[lo:hi])
+    return hi - lo
+
+
+def _python_pass(bounds):
+    from oracle import py_oracle as P
+    syms, a_off, a_len, b_off, b_len = _DATA
+    lo, hi = bounds
+    return len(P.edit_distance_slice((syms[:int(b_off[hi - 1]) + int(b_len[hi - 1])], a_off.tolist(), a_len.tolist(),
+                                      b_off.tolist(), b_len.tolist(), lo, hi)))
+
+
+def cpu_baseline(data, cells_per_pair, budget_s=12.0):
+    """Oracle (C port of the reference's O(NP) edit_distance) on the host cores, bounded sample."""
+    global _DATA
+    _DATA = data
+    cores = max(1, min(16, os.cpu_count() or 1))
+    n = len(data[1])
+    bounds = np.linspace(0, n, cores + 1).astype(int)
+    jobs = [(int(bounds[i]), int(bounds[i + 1])) for i in range(cores)]
+    ctx = multiprocessing.get_context("fork")
+    with ctx.Pool(cores) as pool:
+        pool.map(_oracle_pass, jobs)                       # warm-up (library load, page faults)
+        passes, t0 = 0, time.perf_counter()
+        while time.perf_counter() - t0 < budget_s and passes < 1000:
+            pool.map(_oracle_pass, jobs)
+            passes += 1
+        wall = time.perf_counter() - t0
+        # the reference's own flavour: interpreted Python, one process per core, smaller sample
+        py_n = min(n, 512 * cores)
+        pb = np.linspace(0, py_n, cores + 1).astype(int)
+        t1 = time.perf_counter()
+        pool.map(_python_pass, [(int(pb[i]), int(pb[i + 1])) for i in range(cores)])
+        py_wall = time.perf_counter() - t1
+    pairs = passes * n
+    return {
+        "value": round(pairs * cells_per_pair / wall / 1e9, 3), "unit": "GCUPS", "cores": cores, "kind": "port",
+        "pairs_per_s": round(pairs / wall, 1),
+        "sample": f"{passes} passes over all {n} pairs of the workload, oracle/lcs_oracle.c O(NP) edit_distance, "
+                  f"{cores} processes, {wall:.1f} s wall",
+        "python_restatement": {"value": round(py_n * cells_per_pair / py_wall / 1e9, 3), "unit": "GCUPS",
+                               "pairs_per_s": round(py_n / py_wall, 1), "cores": cores,
+                               "sample": f"{py_n} pairs, oracle/py_oracle.py (interpreted, as the reference), {py_wall:.1f} s wall"},
+    }
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=50)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--pairs", type=int, default=100000)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus and world > 1:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
+    os.environ.setdefault("MALCS_DEVICE", str(local_rank))
+
+    import torch
+    torch.cuda.set_device(local_rank)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+
+    import gen
+    from algebra_amd import _native
+
+    ctx = _native.Context(local_rank)
+    name, cus, mhz = ctx.device_info()
+    data = gen.c2_batch(args.pairs, seed=2 + rank)
+    syms, a_off, a_len, b_off, b_len = data
+    cells = float((a_len.astype(np.float64) * b_len.astype(np.float64)).sum())
+    batch = _native.Batch(ctx, syms, a_off, a_len, b_off, b_len, 4)
+
+    def fence():
+        torch.cuda.synchronize()
+        if dist is not None:
+            dist.barrier()
+            torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        batch.launch_distances()
+    fence()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        batch.launch_distances()
+    fence()
+    elapsed = time.perf_counter() - t0
+    if dist is not None:
+        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+        c = torch.tensor([cells], dtype=torch.float64, device="cuda")
+        dist.all_reduce(c, op=dist.ReduceOp.SUM)
+        total_cells = float(c.item())
+    else:
+        total_cells = cells
+
+    # a checksum of the results so that a wrong kernel cannot hide behind a fast one
+    d = batch.fetch_distances()
+    mean_distance = float(d.mean())
+
+    # dominant kernel: HIP events on the library's stream around `steps` launches
+    kernel_ms = batch.time_distances(args.steps) / args.steps
+    achieved = cells * OPS_PER_CELL / (kernel_ms * 1e-3) / 1e12
+
+    if rank == 0:
+        traffic = None
+        pmc = os.path.join(ROOT, "profiles", "r01_family1_pmc.json")
+        if os.path.exists(pmc):
+            with open(pmc) as f:
+                rec = json.load(f)
+            if rec.get("pairs") == args.pairs:
+                traffic = rec.get("hbm_bytes_per_launch")
+        out = {
+            "metric": "GCUPS (batched LCS edit distance, 1 kb windows)",
+            "value": round(total_cells * args.steps / elapsed / 1e9, 1),
+            "unit": "GCUPS",
+            "pairs_per_s": round(args.pairs * world * args.steps / elapsed, 1),
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": round(elapsed / args.steps * 1e3, 4),
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "u32", "data": "synthetic",
+            "config": {"workload": f"C2: {args.pairs} pairs/GPU, 1 kb reference windows, ~2% indels (seed 2+rank), "
+                                   "packed bit planes resident in HBM", "pairs_per_gpu": args.pairs,
+                       "parallelism": f"independent pairs x {world} rank(s)", "device": name},
+            "mean_distance": round(mean_distance, 3),
+            "roofline": {"bound": "valu", "achieved": round(achieved, 2), "peak": round(PEAK_LANE_OPS / 1e12, 1),
+                         "unit": "T int32 lane-op/s", "frac": round(achieved * 1e12 / PEAK_LANE_OPS, 4),
+                         "traffic": traffic, "kernel": "k_llcs_bitpar<4,2>", "kernel_ms": round(kernel_ms, 4),
+                         "algorithmic": f"{OPS_PER_CELL} lane-op/cell x {cells:.4g} cells/launch"},
+        }
+        if not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(data, cells / args.pairs)
+        print(json.dumps(out), flush=True)
+
+    batch.close()
+    ctx.close()
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -112,3 +112,9 @@ def test_large_inputs_regenerate(idx):
     a, b = gen.large_pair(rec["case"])
     assert digest([a, b]) == rec["input_sha256"]
     assert O.edit_distance(a, b) == rec["distance"]
+
+
+def test_python_restatement_of_edit_distance():
+    from oracle import py_oracle as P
+    for rec in REF["lcs"] + SMALL["lcs"][:200] + MEDIUM["lcs"][:20]:
+        assert P.edit_distance(rec["reference"], rec["observed"]) == rec["edit_distance"]
