@@ -13,7 +13,7 @@ import weakref
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libmalcs.so")
+LIB_PATH = os.environ.get("MALCS_LIB") or os.path.join(_HERE, "libmalcs.so")
 
 MALCS_OK = 0
 PAIR_OK = 0

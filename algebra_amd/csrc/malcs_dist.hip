@@ -14,9 +14,11 @@
 //     the pattern in VGPRs: bit planes P[plane][limb] and the state V[limb]; 64/L pairs share a wave;
 //   * one column costs, per limb, NP v_bitop3_b32 (U), one v_addc_co_u32 (the sum, carry chained
 //     through the lane's limbs) and one v_bitop3_b32 (V');
-//   * the carry between the lanes of a pair travels by DPP (wave_shr:1) as a 0/1 value that is added
-//     to the next lane's lowest limb; only if that addition itself overflows (the limb was all ones)
-//     does the wave take the ripple path, which finishes the propagation exactly;
+//   * the lanes of a pair form a systolic array: lane q works on text column (step - q), so the carry
+//     out of lane q-1 is consumed by lane q one step later.  Carries live in SGPR pairs (lane masks):
+//     limb to limb through v_addc_co_u32, lane to lane as (carry_out << 1) & segmask on the scalar
+//     unit.  No look-ahead, no second pass, exact for any carry length (carries routinely run through
+//     every lane above the DP frontier);
 //   * text symbols come from the packed arena, NP dwords per 32 columns and lane.
 //
 // Algorithmic work: 4 dword ops per 32 cells for DNA = 0.125 lane-op per cell.
@@ -25,53 +27,83 @@
 
 namespace {
 
-__device__ __forceinline__ uint32_t lane_shr1(uint32_t v)
+// One limb of one column: U = V & Match (NP v_bitop3_b32, the match mask never materialises),
+// S = V + U + carry (v_addc_co_u32 with the carry in an SGPR pair, so that it can be handed from limb
+// to limb, from lane to lane and from step to step without touching VALU registers).
+// The two v_bitop3 in front of every v_addc also provide the wait states gfx950 needs between a VALU
+// write of an SGPR and a VALU read of it, which the compiler cannot see inside inline asm.
+template <int NP, bool MASKED> struct limb;
+
+template <> struct limb<2, false> {
+    static __device__ __forceinline__ void step(uint32_t &U, uint32_t &S, uint64_t &cout, uint32_t V, uint64_t cin, uint32_t,
+                                                const uint32_t *P, const uint32_t *x)
+    {
+        asm("v_bitop3_b32 %0, %3, %5, %6 bitop3:0x90\n\tv_bitop3_b32 %0, %0, %7, %8 bitop3:0x90\n\t"
+            "v_addc_co_u32_e64 %1, %2, %3, %0, %4"
+            : "=&v"(U), "=&v"(S), "=&s"(cout) : "v"(V), "s"(cin), "v"(P[0]), "v"(x[0]), "v"(P[1]), "v"(x[1]));
+    }
+};
+template <> struct limb<2, true> {
+    static __device__ __forceinline__ void step(uint32_t &U, uint32_t &S, uint64_t &cout, uint32_t V, uint64_t cin, uint32_t act,
+                                                const uint32_t *P, const uint32_t *x)
+    {
+        asm("v_bitop3_b32 %0, %3, %6, %7 bitop3:0x90\n\tv_bitop3_b32 %0, %0, %8, %9 bitop3:0x90\n\t"
+            "v_and_b32 %0, %0, %5\n\tv_addc_co_u32_e64 %1, %2, %3, %0, %4"
+            : "=&v"(U), "=&v"(S), "=&s"(cout) : "v"(V), "s"(cin), "v"(act), "v"(P[0]), "v"(x[0]), "v"(P[1]), "v"(x[1]));
+    }
+};
+// generic plane counts: the match mask is folded plane by plane in C (the compiler emits v_bitop3),
+// only the carry-chained addition is asm; s_nop 1 supplies the wait states
+template <int NP, bool MASKED> struct limb {
+    static __device__ __forceinline__ void step(uint32_t &U, uint32_t &S, uint64_t &cout, uint32_t V, uint64_t cin, uint32_t act,
+                                                const uint32_t *P, const uint32_t *x)
+    {
+        uint32_t u = V;
+#pragma unroll
+        for (int p = 0; p < NP; p++) u &= ~(P[p] ^ x[p]);
+        if (MASKED) u &= act;
+        U = u;
+        asm("s_nop 1\n\tv_addc_co_u32_e64 %0, %1, %2, %3, %4" : "=v"(S), "=&s"(cout) : "v"(V), "v"(u), "s"(cin));
+    }
+};
+
+// carry out of every lane -> carry into the next lane of the same pair (scalar unit, lane masks).
+// Written as asm so that the value provably stays in SGPRs between the v_addc of one step and the next.
+__device__ __forceinline__ uint64_t carry_to_next_lane(uint64_t cout, uint64_t segmask)
 {
-    // lane i receives lane i-1's value, lane 0 receives 0 (wave_shr:1, old = 0)
-    return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x138, 0xf, 0xf, false);
+    uint64_t cin;
+    asm("s_lshl_b64 %0, %1, 1\n\ts_and_b64 %0, %0, %2" : "=&s"(cin) : "s"(cout), "s"(segmask) : "scc");
+    return cin;
 }
 
-template <int NL, int NP, bool MASKED, bool XL>
-__device__ __forceinline__ void column_step(uint32_t (&V)[NL], const uint32_t (&P)[NP][NL],
-                                            const uint32_t (&x)[NP], uint32_t act, uint32_t notlast)
+// One column for one lane: chain the limbs, return the carry out of the lane's top limb.
+template <int NL, int NP, bool MASKED>
+__device__ __forceinline__ uint64_t column_step(uint32_t (&V)[NL], const uint32_t (&P)[NL][NP],
+                                                const uint32_t (&x)[NP], uint32_t act, uint64_t cin)
 {
-    uint32_t U[NL], S[NL];
-    unsigned c = 0;
+    uint64_t c = cin;
 #pragma unroll
     for (int k = 0; k < NL; k++) {
-        uint32_t u = V[k];
-#pragma unroll
-        for (int p = 0; p < NP; p++) u &= ~(P[p][k] ^ x[p]);
-        if (MASKED) u &= act;
-        U[k] = u;
-        S[k] = __builtin_addc(V[k], u, c, &c);
+        uint32_t U, S;
+        uint64_t co;
+        limb<NP, MASKED>::step(U, S, co, V[k], c, act, P[k], x);
+        V[k] = S | (V[k] ^ U);
+        c = co;
     }
-    if (XL) {
-        uint32_t cv = c ? notlast : 0u;
-        uint32_t cin = lane_shr1(cv);
-        unsigned co;
-        S[0] = __builtin_addc(S[0], cin, 0u, &co);
-        if (__builtin_amdgcn_ballot_w64(co != 0)) {
-            // Rare: the carry-in overflowed limb 0.  Ripple through the lane's limbs, then keep
-            // handing carries to the next lane until none is left (at most L rounds).
-            unsigned r = co;
-#pragma unroll
-            for (int k = 1; k < NL; k++) S[k] = __builtin_addc(S[k], 0u, r, &r);
-            uint32_t cv2 = r ? notlast : 0u;
-            while (__builtin_amdgcn_ballot_w64(cv2 != 0)) {
-                unsigned r2 = lane_shr1(cv2);
-#pragma unroll
-                for (int k = 0; k < NL; k++) S[k] = __builtin_addc(S[k], 0u, r2, &r2);
-                cv2 = r2 ? notlast : 0u;
-            }
-        }
-    }
-#pragma unroll
-    for (int k = 0; k < NL; k++) V[k] = S[k] | (V[k] ^ U[k]);
+    return c;
 }
 
+// The lanes of a pair work as a systolic array: lane q handles text column (step - q), so the carry
+// that leaves lane q-1 in one step is exactly the carry lane q needs in the next step.  It travels
+// as a wave-wide lane mask in SGPRs: (carry_out << 1) & segmask, no VALU work and no look-ahead.
+#ifndef MALCS_UC
+#define MALCS_UC 16
+#endif
+#ifndef MALCS_MINW
+#define MALCS_MINW 8
+#endif
 template <int W, int NP, bool XL>
-__global__ void __launch_bounds__(256)
+__global__ void __launch_bounds__(256, MALCS_MINW)
 k_llcs_bitpar(const uint32_t *__restrict__ planes,
               const uint32_t *__restrict__ a_off, const uint32_t *__restrict__ a_len,
               const uint32_t *__restrict__ b_off, const uint32_t *__restrict__ b_len,
@@ -79,11 +111,11 @@ k_llcs_bitpar(const uint32_t *__restrict__ planes,
               int32_t *__restrict__ dist)
 {
     constexpr int NL = 2 * W;
-    constexpr int UC = NL <= 8 ? 32 : (NL <= 16 ? 8 : 4);   // columns unrolled per inner trip
+    constexpr int UC = NL <= 8 ? MALCS_UC : (NL <= 16 ? 8 : 4);   // columns unrolled per inner trip
     const unsigned L = 1u << logL;
     const unsigned lane = threadIdx.x & 63u;
     const unsigned wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
-    const unsigned q = lane & (L - 1u);
+    const unsigned q = XL ? (lane & (L - 1u)) : 0u;
     const unsigned slot = wave * (64u >> logL) + (lane >> logL);
     const bool valid = slot < count;
     const uint32_t pid = order[first + (valid ? slot : 0u)];
@@ -94,42 +126,67 @@ k_llcs_bitpar(const uint32_t *__restrict__ planes,
     if (!valid) { m = 0; n = 0; }
 
     const uint32_t pblk = (m + 31u) >> 5;
-    uint32_t P[NP][NL], V[NL];
+    uint32_t P[NL][NP], V[NL];
 #pragma unroll
     for (int k = 0; k < NL; k++) {
         const uint32_t g = q * NL + k;
         const bool in = g < pblk;
 #pragma unroll
-        for (int p = 0; p < NP; p++) P[p][k] = in ? planes[po + g * NP + p] : 0u;
+        for (int p = 0; p < NP; p++) P[k][p] = in ? planes[po + g * NP + p] : 0u;
         V[k] = ~0u;
     }
-    const uint32_t notlast = (q != L - 1u) ? 1u : 0u;
+    const uint64_t segmask = XL ? __builtin_amdgcn_ballot_w64(q != 0u) : 0ull;
+    uint64_t zero64;                               // an SGPR pair holding 0 (the asm needs a register, not a literal)
+    asm("s_mov_b64 %0, 0" : "=s"(zero64));
+    uint64_t cin = zero64;
 
-    const uint32_t tblk = (n + 31u) >> 5;
-    for (uint32_t b = 0;; b++) {
-        if (__builtin_amdgcn_ballot_w64(b < tblk) == 0) break;
-        uint32_t t[NP];
+    const int tblk = (int)((n + 31u) >> 5);
+    const int qb = (int)(q >> 5);                  // this lane lags the pair's first lane by q columns
+    const uint32_t qq = q & 31u;
+    uint32_t tprev[NP], tnext[NP];                 // text block of the previous / of the coming block of steps
 #pragma unroll
-        for (int p = 0; p < NP; p++) t[p] = (b < tblk) ? planes[to + b * NP + p] : 0u;
-        const int rem = (int)n - (int)(b * 32u);
-        if (__builtin_amdgcn_ballot_w64(rem < 32) == 0) {
+    for (int p = 0; p < NP; p++) {
+        tprev[p] = 0u;
+        tnext[p] = (qb == 0 && tblk > 0) ? planes[to + p] : 0u;
+    }
+
+    for (int B = 0;; B++) {
+        const int lo = (int)q - 32 * B;            // first and one-past-last valid step of this lane in the block
+        const int hi = (int)(n + q) - 32 * B;
+        if (__builtin_amdgcn_ballot_w64(hi > 0) == 0) break;
+        const int nblk = B + 1 - qb;               // text block whose columns start inside the NEXT block of steps
+        uint32_t w[NP];
+#pragma unroll
+        for (int p = 0; p < NP; p++) {
+            const uint32_t tcur = tnext[p];
+            // prefetch one block ahead so that the load latency hides behind 32 columns of VALU work
+            tnext[p] = (nblk >= 0 && nblk < tblk) ? planes[to + (uint32_t)nblk * NP + p] : 0u;
+            // bit s of w = text bit of column 32*B + s - q
+            w[p] = qq ? __builtin_amdgcn_alignbit(tcur, tprev[p], 32u - qq) : tcur;
+            tprev[p] = tcur;
+        }
+        const uint32_t mlo = lo <= 0 ? ~0u : (lo >= 32 ? 0u : (~0u << lo));
+        const uint32_t mhi = hi >= 32 ? ~0u : (hi <= 0 ? 0u : ((1u << hi) - 1u));
+        const uint32_t vm = mlo & mhi;
+        if (__builtin_amdgcn_ballot_w64(vm != ~0u) == 0) {
 #pragma unroll UC
-            for (int j = 0; j < 32; j++) {
+            for (int s = 0; s < 32; s++) {
                 uint32_t x[NP];
 #pragma unroll
-                for (int p = 0; p < NP; p++) x[p] = (uint32_t)__builtin_amdgcn_sbfe((int)t[p], j, 1);
-                column_step<NL, NP, false, XL>(V, P, x, 0u, notlast);
+                for (int p = 0; p < NP; p++) x[p] = (uint32_t)__builtin_amdgcn_sbfe((int)w[p], s, 1);
+                const uint64_t co = column_step<NL, NP, false>(V, P, x, 0u, cin);
+                cin = XL ? carry_to_next_lane(co, segmask) : zero64;
             }
         } else {
-            // some lane's text ends inside this block: columns past its end must not change V
-            const uint32_t vm = rem >= 32 ? ~0u : (rem <= 0 ? 0u : ((1u << rem) - 1u));
+            // first / last blocks: steps outside [0, n) of a lane's own columns must not change its V
 #pragma unroll UC
-            for (int j = 0; j < 32; j++) {
+            for (int s = 0; s < 32; s++) {
                 uint32_t x[NP];
 #pragma unroll
-                for (int p = 0; p < NP; p++) x[p] = (uint32_t)__builtin_amdgcn_sbfe((int)t[p], j, 1);
-                const uint32_t act = (uint32_t)__builtin_amdgcn_sbfe((int)vm, j, 1);
-                column_step<NL, NP, true, XL>(V, P, x, act, notlast);
+                for (int p = 0; p < NP; p++) x[p] = (uint32_t)__builtin_amdgcn_sbfe((int)w[p], s, 1);
+                const uint32_t act = (uint32_t)__builtin_amdgcn_sbfe((int)vm, s, 1);
+                const uint64_t co = column_step<NL, NP, true>(V, P, x, act, cin);
+                cin = XL ? carry_to_next_lane(co, segmask) : zero64;
             }
         }
     }
@@ -142,7 +199,7 @@ k_llcs_bitpar(const uint32_t *__restrict__ planes,
         const uint32_t mask = vb >= 32 ? ~0u : (vb <= 0 ? 0u : ((1u << vb) - 1u));
         zeros += __popc(~V[k] & mask);
     }
-    for (unsigned s = 1; s < L; s <<= 1) zeros += __shfl_xor(zeros, s);
+    if (XL) for (unsigned s = 1; s < L; s <<= 1) zeros += __shfl_xor(zeros, s);
     if (valid && q == 0) dist[pid] = (int32_t)(m + n - 2u * zeros);
 }
 
