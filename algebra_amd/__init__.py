@@ -5,7 +5,8 @@ libmalcs.so (HIP, gfx950) through the C-ABI in include/malcs.h.
 """
 
 from .lcs import LCSgraph, edit_distance, edit_distance_batch, trim
+from .relations import Relation, compare
 from .variants import Variant, patch
 
-__all__ = ["LCSgraph", "Variant", "edit_distance", "edit_distance_batch", "patch", "trim"]
+__all__ = ["LCSgraph", "Relation", "Variant", "compare", "edit_distance", "edit_distance_batch", "patch", "trim"]
 __version__ = "0.1.0"

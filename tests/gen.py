@@ -206,3 +206,37 @@ def c2_batch(n_pairs, seed=2, length=1000, p=0.01):
     b_off = (np.uint64(n_pairs * length) + np.concatenate([[0], np.cumsum(b_len[:-1], dtype=np.uint64)])).astype(np.uint64)
     syms = np.concatenate([a.reshape(-1), b_flat])
     return syms, a_off, np.full(n_pairs, length, np.uint32), b_off, b_len
+
+
+def clustered_variants(rs, reference, n_clusters, per_cluster, width):
+    """SURVEY 8(d) C4 recipe in small: single-variant alleles packed into hot spots (uniform placement
+    would make every pair trivially disjoint).  Returns a list of (start, end, inserted)."""
+    out = []
+    for _ in range(n_clusters):
+        centre = int(rs.randint(width, len(reference) - width))
+        for _ in range(per_cluster):
+            pos = centre + int(rs.randint(-width // 2, width // 2))
+            kind = rs.randint(0, 3)
+            if kind == 0:                       # deletion
+                out.append((pos, pos + int(rs.randint(1, 4)), ""))
+            elif kind == 1:                     # insertion
+                out.append((pos, pos, random_seq(rs, int(rs.randint(1, 4)))))
+            else:                               # substitution / delins
+                k = int(rs.randint(1, 3))
+                out.append((pos, pos + k, random_seq(rs, int(rs.randint(1, 3)))))
+    return out
+
+
+def matrix_case(seed=6006, length=400, n_clusters=5, per_cluster=10, width=16, tandem=True):
+    rs = np.random.RandomState(seed)
+    reference = random_seq(rs, length)
+    if tandem:                                   # half of the hot spots sit on tandem repeats
+        pieces, pos = [], 0
+        for k in range(n_clusters // 2 + 1):
+            cut = (k + 1) * length // (n_clusters // 2 + 2)
+            unit = random_seq(rs, int(rs.randint(1, 4)))
+            pieces.append(reference[pos:cut] + unit * int(rs.randint(4, 9)))
+            pos = cut
+        pieces.append(reference[pos:])
+        reference = "".join(pieces)
+    return {"reference": reference, "variants": clustered_variants(rs, reference, n_clusters, per_cluster, width)}

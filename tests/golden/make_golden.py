@@ -263,8 +263,22 @@ def main():
     for case in gen.relation_cases():
         r, a, b = case["reference"], case["lhs"], case["rhs"]
         rel.append({"reference": r, "lhs": a, "rhs": b, "relation": sequence_based.compare(r, a, b).value})
+    # all-vs-all matrix of graph_based.compare over clustered single-variant alleles (C4 in small)
+    codes = {relation: code for code, relation in enumerate(Relation)}
+    matrices = []
+    for params_ in ({}, {"seed": 6007, "length": 250, "n_clusters": 3, "per_cluster": 14, "width": 10}):
+        case = gen.matrix_case(**params_)
+        graphs = [LCSgraph.from_variant(case["reference"], [Variant(*v)]) for v in case["variants"]]
+        labels = [[codes[graph_based.compare(case["reference"], a, b)] for b in graphs] for a in graphs]
+        variant_labels = [[codes[variant_based.compare(case["reference"], [Variant(*a)], [Variant(*b)])]
+                           for b in case["variants"][:12]] for a in case["variants"][:12]]
+        supremal_labels = [[codes[supremal_based.compare(case["reference"], a.supremal, b.supremal)]
+                            for b in graphs[:12]] for a in graphs[:12]]
+        matrices.append({"params": params_, "reference": case["reference"], "variants": [list(v) for v in case["variants"]],
+                         "supremals": [var(g.supremal) for g in graphs], "distances": [g.distance for g in graphs],
+                         "labels": labels, "variant_labels_12": variant_labels, "supremal_labels_12": supremal_labels})
     with open(os.path.join(HERE, "random_sequences.json"), "w") as f:
-        json.dump({"sequences": seqs, "relations": rel}, f, separators=(",", ":"))
+        json.dump({"sequences": seqs, "relations": rel, "matrices": matrices}, f, separators=(",", ":"))
     print(f"random_sequences.json: {len(seqs)} sequence cases, {len(rel)} relation triples  ({time.time()-t0:.1f}s)")
 
     # ---- F3: large shapes, hashes only; inputs regenerated from the seed by tests/gen.py ----
