@@ -1,0 +1,118 @@
+"""GPU parity tests of the callers of the LCS path: relations (four flavours, matrix) and the
+extractor, against fixtures captured from the reference."""
+
+import numpy as np
+import pytest
+
+from conftest import load_golden
+from util import digest
+import gen
+
+pytestmark = pytest.mark.gpu
+
+REF = load_golden("reference_tests.json")
+SEQS = load_golden("random_sequences.json")
+LARGE = load_golden("large.json")
+
+
+def test_sequence_based_relations():
+    from algebra_amd.relations import Relation, sequence_based as sb
+    for rec in REF["relations"]["sequence_based"] + SEQS["relations"]:
+        r, a, b = rec["reference"], rec["lhs"], rec["rhs"]
+        want = Relation(rec["relation"])
+        assert sb.compare(r, a, b) == want, (r, a, b)
+    for rec in REF["relations"]["sequence_based"]:
+        r, a, b = rec["reference"], rec["lhs"], rec["rhs"]
+        want = Relation(rec["relation"])
+        assert sb.are_equivalent(r, a, b) == (want == Relation.EQUIVALENT)
+        assert sb.contains(r, a, b) == (want == Relation.CONTAINS)
+        assert sb.is_contained(r, a, b) == (want == Relation.IS_CONTAINED)
+        assert sb.are_disjoint(r, a, b) == (want == Relation.DISJOINT)
+        assert sb.have_overlap(r, a, b) == (want == Relation.OVERLAP)
+
+
+def test_variant_and_supremal_based_relations():
+    import algebra_amd
+    from algebra_amd.relations import Relation, supremal_based, variant_based
+    from algebra_amd.variants import Variant
+    for rec in REF["relations"]["variant_based"]:
+        lhs, rhs = [Variant(*v) for v in rec["lhs"]], [Variant(*v) for v in rec["rhs"]]
+        want = Relation(rec["relation"])
+        assert algebra_amd.compare(rec["reference"], lhs, rhs) == want
+        assert variant_based.contains(rec["reference"], lhs, rhs) == (want == Relation.CONTAINS)
+        assert variant_based.are_disjoint(rec["reference"], lhs, rhs) == (want == Relation.DISJOINT)
+    for rec in REF["relations"]["supremal_based"]:
+        lhs, rhs = Variant(*rec["lhs"]), Variant(*rec["rhs"])
+        want = Relation(rec["relation"])
+        assert supremal_based.compare(rec["reference"], lhs, rhs) == want
+        assert supremal_based.are_equivalent(rec["reference"], lhs, rhs) == (want == Relation.EQUIVALENT)
+        assert supremal_based.contains(rec["reference"], lhs, rhs) == (want == Relation.CONTAINS)
+        assert supremal_based.is_contained(rec["reference"], lhs, rhs) == (want == Relation.IS_CONTAINED)
+        assert supremal_based.are_disjoint(rec["reference"], lhs, rhs) == (want == Relation.DISJOINT)
+        assert supremal_based.have_overlap(rec["reference"], lhs, rhs) == (want == Relation.OVERLAP)
+    codes = list(Relation)
+    case = SEQS["matrices"][0]
+    alleles = [[Variant(*v)] for v in case["variants"][:12]]
+    sup = [Variant(*v) for v in case["supremals"][:12]]
+    for i in range(12):
+        for j in range(12):
+            assert variant_based.compare(case["reference"], alleles[i], alleles[j]) == codes[case["variant_labels_12"][i][j]]
+            assert supremal_based.compare(case["reference"], sup[i], sup[j]) == codes[case["supremal_labels_12"][i][j]]
+
+
+@pytest.mark.parametrize("tile", [16, 256])
+def test_compare_matrix(tile):
+    """C4 in small: supremal graphs on the GPU, then the tiled all-vs-all matrix."""
+    from algebra_amd.lcs import LCSgraph
+    from algebra_amd.relations import compare_matrix
+    from algebra_amd.variants import Variant
+    for case in SEQS["matrices"]:
+        graphs = [LCSgraph.from_variant(case["reference"], [Variant(*v)]) for v in case["variants"]]
+        assert [[g.supremal.start, g.supremal.end, g.supremal.sequence] for g in graphs] == case["supremals"]
+        assert [g.distance for g in graphs] == case["distances"]
+        stats = {}
+        labels = compare_matrix(case["reference"], graphs, tile=tile, stats=stats)
+        assert labels.tolist() == case["labels"]
+        assert stats["dp_pairs"] > 0
+
+
+def test_extract_sequence_canonical_and_hgvs():
+    from algebra_amd.extractor import extract_sequence, to_hgvs
+    for rec in REF["sequences"] + SEQS["sequences"]:
+        variants, graph = extract_sequence(rec["reference"], rec["observed"])
+        got = [[v.start, v.end, v.sequence] for v in variants]
+        if "canonical" in rec:
+            assert got == rec["canonical"], (rec["reference"], rec["observed"])
+        else:
+            assert digest(got) == rec["canonical_sha256"]
+        if "hgvs" in rec:
+            assert to_hgvs(variants, rec["reference"]) == rec["hgvs"]
+        else:
+            with pytest.raises(Exception) as exc:
+                to_hgvs(variants, rec["reference"])
+            assert [type(exc.value).__name__, str(exc.value)] == rec["hgvs_error"]
+
+
+def test_extract_like_the_reference_tests():
+    from algebra_amd.extractor import extract, extract_sequence, extract_supremal, to_hgvs
+    from algebra_amd.variants import Variant
+    rec = max((r for r in REF["sequences"] if "hgvs" in r), key=lambda r: len(r["reference"]))
+    variants, _ = extract_sequence(rec["reference"], rec["observed"])
+    assert to_hgvs(variants, rec["reference"]) == rec["hgvs"]
+    variants, graph = extract("GTGTGTTTTTTTAACAGGGA", [Variant(8, 9, "")])
+    assert graph.supremal == Variant(5, 12, "TTTTTT")
+    variants2, _ = extract_supremal("GTGTGTTTTTTTAACAGGGA", graph.supremal)
+    assert variants2 == variants
+
+
+@pytest.mark.parametrize("idx", [i for i, r in enumerate(LARGE["from_sequence"]) if r["len_reference"] <= 16000])
+def test_extract_sequence_10kb(idx):
+    """BASELINE config 3: extract_sequence on 10 kb windows with tandem-repeat indels."""
+    from algebra_amd.extractor import extract_sequence, to_hgvs
+    rec = LARGE["from_sequence"][idx]
+    a, b = gen.large_pair(rec["case"])
+    variants, graph = extract_sequence(a, b)
+    assert graph.distance == rec["distance"]
+    assert len(variants) == rec["n_variants"]
+    assert digest([[v.start, v.end, v.sequence] for v in variants]) == rec["canonical_sha256"]
+    assert digest(to_hgvs(variants, a)) == rec["hgvs_sha256"]
