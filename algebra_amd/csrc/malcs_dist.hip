@@ -203,6 +203,167 @@ k_llcs_bitpar(const uint32_t *__restrict__ planes,
     if (valid && q == 0) dist[pid] = (int32_t)(m + n - 2u * zeros);
 }
 
+// ------------------------------------------------------------------------------------------------
+// Banded variant for long, similar pairs (shorter sequence beyond what 64 lanes x 16 words hold, or
+// simply long): one wave per pair, the 64 lanes hold a window of 64 row groups (G = 64*W rows each)
+// that slides down the matrix with the band of diagonals an alignment of cost <= T can visit
+// (k = col - row in [-(T-delta)/2, delta + (T-delta)/2], delta = n - m >= 0).
+//
+// Row group u always works on text column (step - u) -- the same systolic schedule as above, so the
+// carry chain is unchanged.  Every 32 steps the window may advance by one group: registers move one
+// lane down, the group that leaves is frozen (its zero bits are banked), a fresh group (V = all ones)
+// enters in lane 63.  Freezing a group and starting a group late both restrict the DP to paths that
+// stay inside the window, so the result D' is exact whenever D' <= T (then no alignment of cost <= D'
+// leaves the band); the host retries with a wider window otherwise.
+__device__ __forceinline__ uint64_t carry_window_down(uint64_t cin)
+{
+    uint64_t out;
+    asm("s_lshr_b64 %0, %1, 1" : "=s"(out) : "s"(cin) : "scc");
+    return out;
+}
+
+template <int W, int NP>
+__global__ void __launch_bounds__(64)
+k_llcs_band(const uint32_t *__restrict__ planes,
+            const uint32_t *__restrict__ a_off, const uint32_t *__restrict__ a_len,
+            const uint32_t *__restrict__ b_off, const uint32_t *__restrict__ b_len,
+            const uint32_t *__restrict__ work, const int32_t *__restrict__ thresh, int32_t *__restrict__ out)
+{
+    constexpr int NL = 2 * W;
+    constexpr int G = 64 * W;
+    constexpr int UC = NL <= 4 ? 16 : (NL <= 8 ? 8 : 4);
+    const unsigned lane = threadIdx.x;
+    const uint32_t pid = work[blockIdx.x];
+    const uint32_t la = a_len[pid], lb = b_len[pid];
+    uint32_t m, n, po, to;
+    if (la <= lb) { m = la; n = lb; po = a_off[pid]; to = b_off[pid]; }
+    else          { m = lb; n = la; po = b_off[pid]; to = a_off[pid]; }
+    const int T = thresh[blockIdx.x];
+    const int delta = (int)(n - m);
+    const int kmax = delta + (T > delta ? (T - delta) / 2 : 0);
+    const uint32_t pblk = (m + 31u) >> 5;
+    const int tblk = (int)((n + 31u) >> 5);
+
+    // lowest row group still needed at step t0
+    auto sigma_at = [&](int t0) -> int { const int v = t0 - G + 1 - kmax; return v <= 0 ? 0 : (v + G) / (G + 1); };
+    auto load_group = [&](uint32_t u, uint32_t (&P)[NL][NP]) {
+#pragma unroll
+        for (int k = 0; k < NL; k++) {
+            const uint32_t g = u * NL + k;
+            const bool in = g < pblk;
+#pragma unroll
+            for (int p = 0; p < NP; p++) P[k][p] = in ? planes[po + g * NP + p] : 0u;
+        }
+    };
+    auto zeros_of = [&](uint32_t u, const uint32_t (&V)[NL]) -> uint32_t {
+        uint32_t z = 0;
+#pragma unroll
+        for (int k = 0; k < NL; k++) {
+            const long long vb = (long long)m - (long long)(u * NL + k) * 32ll;
+            const uint32_t mask = vb >= 32 ? ~0u : (vb <= 0 ? 0u : ((1u << vb) - 1u));
+            z += __popc(~V[k] & mask);
+        }
+        return z;
+    };
+    auto load_text = [&](int B, uint32_t u, uint32_t (&tc)[NP], uint32_t (&tp)[NP]) {
+        const int blk = B - (int)(u >> 5);
+#pragma unroll
+        for (int p = 0; p < NP; p++) {
+            tc[p] = (blk >= 0 && blk < tblk) ? planes[to + (uint32_t)blk * NP + p] : 0u;
+            tp[p] = (blk >= 1 && blk - 1 < tblk) ? planes[to + (uint32_t)(blk - 1) * NP + p] : 0u;
+        }
+    };
+
+    int sigma = 0;
+    uint32_t u = lane;
+    uint32_t P[NL][NP], V[NL];
+    load_group(u, P);
+#pragma unroll
+    for (int k = 0; k < NL; k++) V[k] = ~0u;
+    uint32_t frozen = 0;
+    const uint64_t segmask = ~1ull;
+    uint64_t cin;
+    asm("s_mov_b64 %0, 0" : "=s"(cin));
+
+    const int u_last = m ? (int)((m - 1u) / G) : 0;
+    const int t_end = (int)n - 1 + u_last;
+    uint32_t tc[NP], tp[NP];
+    load_text(0, u, tc, tp);
+
+    for (int B = 0; 32 * B <= t_end; B++) {
+        const int sigma_next = sigma_at(32 * (B + 1));
+        uint32_t tcn[NP], tpn[NP];
+        load_text(B + 1, (uint32_t)sigma_next + lane, tcn, tpn);      // prefetch for the next block
+        const uint32_t qq = u & 31u;
+        uint32_t w[NP];
+#pragma unroll
+        for (int p = 0; p < NP; p++) w[p] = qq ? __builtin_amdgcn_alignbit(tc[p], tp[p], 32u - qq) : tc[p];
+        const long long lo = (long long)u - 32ll * B;
+        const long long hi = (long long)n + (long long)u - 32ll * B;
+        const uint32_t mlo = lo <= 0 ? ~0u : (lo >= 32 ? 0u : (~0u << lo));
+        const uint32_t mhi = hi >= 32 ? ~0u : (hi <= 0 ? 0u : ((1u << hi) - 1u));
+        const uint32_t vm = mlo & mhi;
+        if (__builtin_amdgcn_ballot_w64(vm != ~0u) == 0) {
+#pragma unroll UC
+            for (int s = 0; s < 32; s++) {
+                uint32_t x[NP];
+#pragma unroll
+                for (int p = 0; p < NP; p++) x[p] = (uint32_t)__builtin_amdgcn_sbfe((int)w[p], s, 1);
+                const uint64_t co = column_step<NL, NP, false>(V, P, x, 0u, cin);
+                cin = carry_to_next_lane(co, segmask);
+            }
+        } else {
+#pragma unroll UC
+            for (int s = 0; s < 32; s++) {
+                uint32_t x[NP];
+#pragma unroll
+                for (int p = 0; p < NP; p++) x[p] = (uint32_t)__builtin_amdgcn_sbfe((int)w[p], s, 1);
+                const uint32_t act = (uint32_t)__builtin_amdgcn_sbfe((int)vm, s, 1);
+                const uint64_t co = column_step<NL, NP, true>(V, P, x, act, cin);
+                cin = carry_to_next_lane(co, segmask);
+            }
+        }
+        // slide the window: the top group is frozen, everything moves one lane down
+        for (; sigma < sigma_next; sigma++) {
+            if (lane == 0) frozen += zeros_of(u, V);
+#pragma unroll
+            for (int k = 0; k < NL; k++) {
+                V[k] = __shfl_down(V[k], 1);
+#pragma unroll
+                for (int p = 0; p < NP; p++) P[k][p] = __shfl_down(P[k][p], 1);
+            }
+            u += 1;
+            if (lane == 63) {
+                load_group(u, P);
+#pragma unroll
+                for (int k = 0; k < NL; k++) V[k] = ~0u;
+            }
+            cin = carry_window_down(cin);
+        }
+#pragma unroll
+        for (int p = 0; p < NP; p++) { tc[p] = tcn[p]; tp[p] = tpn[p]; }
+    }
+
+    uint32_t zeros = frozen + zeros_of(u, V);
+    for (unsigned s = 1; s < 64; s <<= 1) zeros += __shfl_xor(zeros, s);
+    if (lane == 0) out[blockIdx.x] = (int32_t)(m + n - 2u * zeros);
+}
+
+typedef void (*band_kernel_t)(const uint32_t *, const uint32_t *, const uint32_t *, const uint32_t *, const uint32_t *,
+                              const uint32_t *, const int32_t *, int32_t *);
+template <int NP>
+band_kernel_t pick_band(int W)
+{
+    switch (W) {
+    case 1: return k_llcs_band<1, NP>;
+    case 2: return k_llcs_band<2, NP>;
+    case 4: return k_llcs_band<4, NP>;
+    case 8: if constexpr (NP <= 4) return k_llcs_band<8, NP>; else return nullptr;
+    case 16: if constexpr (NP <= 3) return k_llcs_band<16, NP>; else return nullptr;
+    default: return nullptr;
+    }
+}
+
 typedef void (*dist_kernel_t)(const uint32_t *, const uint32_t *, const uint32_t *, const uint32_t *,
                               const uint32_t *, const uint32_t *, uint32_t, uint32_t, int, int32_t *);
 
@@ -229,6 +390,7 @@ uint32_t pow2ceil(uint32_t x) { uint32_t p = 1; while (p < x) p <<= 1; return p;
 int malcs_dist_plan(malcs_batch *b)
 {
     const uint64_t n = b->n_pairs;
+    b->band_pairs.clear();
     const int wmax = max_words_per_lane(b->n_planes);
     std::vector<uint8_t> cls(n);
     // class id = index into table of (W, logL)
@@ -248,11 +410,10 @@ int malcs_dist_plan(malcs_batch *b)
         } else {
             W = 4;
             while ((uint32_t)W * 64u < words && W < wmax) W *= 2;
-            if ((uint32_t)W * 64u < words) {
-                malcs_set_error("pair %llu: shorter sequence has %u symbols; the distance kernels hold at most %u "
-                                "symbols of it with %d bit planes", (unsigned long long)i, m, (uint32_t)wmax * 64u * 64u,
-                                b->n_planes);
-                return MALCS_ERR_TOO_LONG;
+            if ((uint32_t)W * 64u < words) {      // too long for a resident pattern: sliding-window kernel
+                b->band_pairs.push_back((uint32_t)i);
+                cls[i] = 255;
+                continue;
             }
             uint32_t lanes = pow2ceil((words + (uint32_t)W - 1u) / (uint32_t)W);
             while ((1u << logL) < lanes) logL++;
@@ -260,10 +421,10 @@ int malcs_dist_plan(malcs_batch *b)
         cls[i] = (uint8_t)class_of(W, logL);
     }
     std::vector<uint32_t> cnt(table.size() + 1, 0);
-    for (uint64_t i = 0; i < n; i++) cnt[cls[i] + 1]++;
+    for (uint64_t i = 0; i < n; i++) if (cls[i] != 255) cnt[cls[i] + 1]++;
     for (size_t c = 0; c < table.size(); c++) cnt[c + 1] += cnt[c];
     std::vector<uint32_t> order(n), pos(cnt.begin(), cnt.end() - 1);
-    for (uint64_t i = 0; i < n; i++) order[pos[cls[i]]++] = (uint32_t)i;
+    for (uint64_t i = 0; i < n; i++) if (cls[i] != 255) order[pos[cls[i]]++] = (uint32_t)i;
     b->dist_buckets.clear();
     for (size_t c = 0; c < table.size(); c++) {
         dist_bucket k;
@@ -299,5 +460,73 @@ int malcs_dist_launch(malcs_batch *b)
                            b->d_b_off, b->d_b_len, b->d_order, k.first, k.count, logL, b->d_dist);
         MALCS_HIP(hipGetLastError());
     }
+    if (!b->band_pairs.empty()) return malcs_dist_band(b, b->band_pairs, nullptr);
     return MALCS_OK;
+}
+
+// Largest threshold a window of 64 groups of G = 64*W rows covers (see k_llcs_band): the groups needed
+// during one block of 32 steps must fit, u_max(t0 + 31) - u_min(t0) + 1 <= 64.
+static int band_capacity(int W) { const int G = 64 * W; return 61 * (G + 1) - G - 64; }
+
+// Distances of long pairs with the sliding-window kernel; widens the window until the result is exact.
+// Synchronous.  Results go to b->d_dist[pid] and, if `host_out` is given, to host_out[k] for pairs[k].
+int malcs_dist_band(malcs_batch *b, const std::vector<uint32_t> &pairs, int32_t *host_out)
+{
+    hipStream_t st = b->ctx->stream;
+    const int wmax = max_words_per_lane(b->n_planes);
+    std::vector<uint32_t> todo(pairs);
+    std::vector<size_t> slot_of(pairs.size());
+    for (size_t i = 0; i < pairs.size(); i++) slot_of[i] = i;
+    std::vector<int32_t> result(pairs.size(), -1);
+    uint32_t *d_work = nullptr; int32_t *d_thresh = nullptr, *d_out = nullptr;
+    MALCS_HIP(hipMalloc(&d_work, pairs.size() * 4)); MALCS_HIP(hipMalloc(&d_thresh, pairs.size() * 4)); MALCS_HIP(hipMalloc(&d_out, pairs.size() * 4));
+    int rc = MALCS_OK;
+    for (int W = 1; W <= wmax && !todo.empty(); W *= 2) {
+        const int T = band_capacity(W);
+        std::vector<uint32_t> work; std::vector<size_t> slots; std::vector<int32_t> thresh;
+        std::vector<uint32_t> later; std::vector<size_t> later_slots;
+        for (size_t i = 0; i < todo.size(); i++) {
+            const uint32_t pid = todo[i];
+            const int64_t delta = std::llabs((int64_t)b->a_len[pid] - (int64_t)b->b_len[pid]);
+            if (delta > T) { later.push_back(pid); later_slots.push_back(slot_of[i]); continue; }
+            work.push_back(pid); slots.push_back(slot_of[i]); thresh.push_back(T);
+        }
+        if (!work.empty()) {
+            band_kernel_t fn = nullptr;
+            switch (b->n_planes) {
+            case 2: fn = pick_band<2>(W); break;
+            case 3: fn = pick_band<3>(W); break;
+            case 4: fn = pick_band<4>(W); break;
+            case 8: fn = pick_band<8>(W); break;
+            }
+            if (!fn) { rc = MALCS_ERR_INTERNAL; malcs_set_error("no band kernel for W=%d planes=%d", W, b->n_planes); break; }
+            std::vector<int32_t> got(work.size());
+            hipMemcpyAsync(d_work, work.data(), work.size() * 4, hipMemcpyHostToDevice, st);
+            hipMemcpyAsync(d_thresh, thresh.data(), work.size() * 4, hipMemcpyHostToDevice, st);
+            hipLaunchKernelGGL(fn, dim3((uint32_t)work.size()), dim3(64), 0, st, b->d_planes, b->d_a_off, b->d_a_len,
+                               b->d_b_off, b->d_b_len, d_work, d_thresh, d_out);
+            hipMemcpyAsync(got.data(), d_out, work.size() * 4, hipMemcpyDeviceToHost, st);
+            hipError_t e = hipStreamSynchronize(st);
+            if (e != hipSuccess) { rc = MALCS_ERR_HIP; malcs_set_error("band kernel failed: %s", hipGetErrorString(e)); break; }
+            for (size_t i = 0; i < work.size(); i++) {
+                if (got[i] <= T) result[slots[i]] = got[i];               // exact: no cheaper alignment can leave the band
+                else { later.push_back(work[i]); later_slots.push_back(slots[i]); }
+            }
+        }
+        todo.swap(later); slot_of.swap(later_slots);
+    }
+    if (rc == MALCS_OK && !todo.empty()) {
+        malcs_set_error("pair %u: sequences of %u and %u symbols differ by more than the widest window (%d edits with %d bit planes) covers",
+                        todo[0], b->a_len[todo[0]], b->b_len[todo[0]], band_capacity(wmax), b->n_planes);
+        rc = MALCS_ERR_TOO_LONG;
+    }
+    if (rc == MALCS_OK) {
+        for (size_t i = 0; i < pairs.size(); i++) {
+            hipMemcpyAsync(b->d_dist + pairs[i], &result[i], 4, hipMemcpyHostToDevice, st);
+            if (host_out) host_out[i] = result[i];
+        }
+        hipStreamSynchronize(st);
+    }
+    hipFree(d_work); hipFree(d_thresh); hipFree(d_out);
+    return rc;
 }

@@ -45,6 +45,7 @@ struct malcs_batch {
     // host mirrors
     std::vector<uint32_t> a_off, a_len, b_off, b_len;   // dword offsets into d_planes / lengths in symbols
     std::vector<dist_bucket> dist_buckets;
+    std::vector<uint32_t> band_pairs;    // pairs too long for a resident pattern: sliding-window kernel
     uint64_t arena_dwords = 0;
     uint32_t max_len = 0;
 };
@@ -57,3 +58,4 @@ int malcs_pack_launch(malcs_ctx *ctx, const uint8_t *d_syms, const uint64_t *d_s
 // malcs_dist.hip
 int malcs_dist_plan(malcs_batch *b);
 int malcs_dist_launch(malcs_batch *b);
+int malcs_dist_band(malcs_batch *b, const std::vector<uint32_t> &pairs, int32_t *host_out);

@@ -77,6 +77,35 @@ def test_edit_distance_long_patterns(native):
     assert got.tolist() == [O.edit_distance(a, b) for a, b in pairs]
 
 
+def test_edit_distance_sliding_window(native):
+    """Sequences longer than a resident pattern (> 65 536): sliding-window kernel, incl. the 100 kb and
+    1 Mb pairs whose distances were captured from the reference."""
+    from oracle import oracle as O
+    import algebra_amd
+    pairs, want = [], []
+    for rec in LARGE["from_sequence"]:
+        if rec["len_reference"] > 16000:
+            a, b = gen.large_pair(rec["case"])
+            assert digest([a, b]) == rec["input_sha256"]
+            pairs.append((a, b))
+            want.append(rec["distance"])
+    rs = np.random.RandomState(11)
+    for m, p in ((70000, 0.001), (100000, 0.01), (200000, 0.003), (300000, 0.02), (66000, 0.08)):
+        a = gen.large_pair({"kind": "mutate", "seed": m, "length": m, "p": 0.0})[0]
+        b = gen.mutate(rs, a, p, p)
+        pairs.append((a, b))
+        want.append(O.edit_distance(a, b))
+    a = pairs[-1][0]
+    for x, y in ((a, a[:-5000]), (a[3000:], a), (a, a), (a, a[:100] + a[40000:])):
+        pairs.append((x, y))
+        want.append(O.edit_distance(x, y))
+    got = algebra_amd.edit_distance_batch(pairs)          # one batch: mixes window widths
+    assert got.tolist() == want
+    short = ("ACGT" * 20, "ACGA" * 20)
+    mixed = algebra_amd.edit_distance_batch([pairs[0], short, pairs[3]])
+    assert mixed.tolist() == [want[0], O.edit_distance(*short), want[3]]
+
+
 def test_edit_distance_c2_full_size(native):
     """BASELINE config 2 at full size: 100k pairs of 1 kb windows, ~2% indels."""
     from oracle import oracle as O
