@@ -17,10 +17,13 @@
 #include <new>
 #include <thread>
 
-int malcs_graph_launch_forward(malcs_batch *b, int W, int logL, const uint32_t *d_work, uint32_t count,
-                               uint32_t *d_scratch, const uint64_t *d_sc_off, int32_t *d_dist);
-int malcs_graph_launch_reach(malcs_batch *b, int W, int logL, const uint32_t *d_work, uint32_t count,
-                             const uint32_t *d_scratch, const uint64_t *d_sc_off, const uint8_t *d_skip,
+int malcs_graph_max_band_words(int n_planes);
+int malcs_graph_launch_forward(malcs_batch *b, int W, int logL, bool band, const uint32_t *d_work, uint32_t count,
+                               uint32_t *d_scratch, const uint64_t *d_sc_off, const int32_t *d_kmin,
+                               const int32_t *d_kmax, const int32_t *d_rw, int32_t *d_dist_out);
+int malcs_graph_launch_reach(malcs_batch *b, int W, int logL, bool band, const uint32_t *d_work, uint32_t count,
+                             const uint32_t *d_scratch, const uint64_t *d_sc_off, const int32_t *d_kmin,
+                             const int32_t *d_kmax, const int32_t *d_rw, const int32_t *d_llcs, const uint8_t *d_skip,
                              void *d_events, const uint64_t *d_ev_off, const uint32_t *d_ev_cap, uint32_t *d_ev_cnt);
 int malcs_graph_launch_compact(malcs_ctx *ctx, const void *d_events, const uint64_t *d_ev_off, const uint32_t *d_ev_n,
                                const uint64_t *d_out_off, uint32_t count, void *d_out);
@@ -220,7 +223,7 @@ void build_graph(int64_t m, int64_t n, int64_t shift, const std::vector<run> &ru
     }
 }
 
-struct launch_class { int W, logL; std::vector<uint32_t> pairs; };
+struct launch_class { int W, logL; bool band; std::vector<uint32_t> pairs; };
 
 template <typename T> struct dev_buf {
     T *p = nullptr;
@@ -251,31 +254,53 @@ static int graph_batch(malcs_batch *b, const int64_t *shift, const int64_t *max_
     std::vector<std::vector<event>> pair_events(N);
     std::vector<uint8_t> has_runs(N, 0);
 
-    // launch classes: the device needs 64*W*L >= m + 1 bits per pair (vertex rows 0..m)
+    // exact distances first (kernel family 1): they decide max_distance, the band and the event budget
+    std::vector<int32_t> dist(N);
+    if (N) {
+        int rc = malcs_dist_launch(b);
+        if (rc) return rc;
+        MALCS_HIP(hipMemcpyAsync(dist.data(), b->d_dist, N * 4ull, hipMemcpyDeviceToHost, st));
+        MALCS_HIP(hipStreamSynchronize(st));
+    }
+
+    // launch classes.  Short windows keep all their row groups resident (L lanes per pair, several pairs per
+    // wave); longer ones get a wave each whose 64 lanes slide along the band given by the distance.
+    const int band_wmax = malcs_graph_max_band_words(b->n_planes);
+    auto band_capacity = [](int W) { const int G = 64 * W; return 61 * (G + 1) - G - 64; };
     std::vector<launch_class> classes;
     for (uint64_t i = 0; i < N; i++) {
         const uint32_t m = b->a_len[i], n = b->b_len[i];
         pair_graph &G = out->g[i];
-        if (m == 0 || n == 0) {                       // no DP needed: LLCS = 0
-            G.distance = (int64_t)m + n;
-            continue;
-        }
-        const uint32_t words = m / 64u + 1u;
-        int W, logL = 0;
-        if (words <= 4) W = (int)pow2ceil(words);
-        else {
-            W = 4;
-            const uint32_t lanes = pow2ceil((words + 3u) / 4u);
-            if (lanes > 64u) {
-                malcs_set_error("pair %llu: reference window of %u symbols exceeds the %u the graph kernels hold",
-                                (unsigned long long)i, m, 64u * 4u * 64u - 1u);
-                return MALCS_ERR_TOO_LONG;
+        G.distance = dist[i];
+        const int64_t md = max_distance ? max_distance[i] : 0;
+        if (md && G.distance > md) { G.status = MALCS_PAIR_MAX_DISTANCE_EXCEEDED; continue; }
+        if (m == 0 || n == 0) continue;               // no DP needed: LLCS = 0
+        int W = 0, logL = 0;
+        bool band = false;
+        if (m < 4096u) {
+            const uint32_t words = m / 64u + 1u;
+            if (words <= 4) W = (int)pow2ceil(words);
+            else { W = 4; const uint32_t lanes = pow2ceil((words + 3u) / 4u); while ((1u << logL) < lanes) logL++; }
+        } else {
+            band = true;
+            logL = 6;
+            for (W = 1; W <= band_wmax && band_capacity(W) < G.distance + 2; W *= 2) {}
+            if (W > band_wmax) {
+                if (m < 16384u) {                       // too divergent for a band: all groups resident
+                    band = false; W = 4; logL = 0;
+                    const uint32_t lanes = pow2ceil((m / 64u + 1u + 3u) / 4u);
+                    while ((1u << logL) < lanes) logL++;
+                } else {
+                    malcs_set_error("pair %llu: windows of %u and %u symbols at distance %lld exceed the widest band "
+                                    "(%d edits) the graph kernels hold", (unsigned long long)i, m, n, (long long)G.distance,
+                                    band_capacity(band_wmax) - 2);
+                    return MALCS_ERR_TOO_LONG;
+                }
             }
-            while ((1u << logL) < lanes) logL++;
         }
         size_t c = 0;
-        for (; c < classes.size(); c++) if (classes[c].W == W && classes[c].logL == logL) break;
-        if (c == classes.size()) classes.push_back({W, logL, {}});
+        for (; c < classes.size(); c++) if (classes[c].W == W && classes[c].logL == logL && classes[c].band == band) break;
+        if (c == classes.size()) classes.push_back({W, logL, band, {}});
         classes[c].pairs.push_back((uint32_t)i);
         has_runs[i] = 1;
     }
@@ -287,20 +312,31 @@ static int graph_batch(malcs_batch *b, const int64_t *shift, const int64_t *max_
     float ms_fwd = 0, ms_reach = 0;
     dev_buf<uint32_t> d_work, d_evcap, d_evcnt, d_scratch;
     dev_buf<uint64_t> d_scoff, d_evoff, d_outoff;
+    dev_buf<int32_t> d_kmin, d_kmax, d_rw, d_llcs, d_fdist;
     dev_buf<uint8_t> d_skip;
     dev_buf<event> d_events, d_packed;
 
     for (const launch_class &lc : classes) {
-        const uint64_t NLtot = (uint64_t)(2 * lc.W) << lc.logL;
+        const uint64_t NL = 2ull * lc.W;
+        const int logG = lc.W == 1 ? 6 : (lc.W == 2 ? 7 : (lc.W == 4 ? 8 : 9));
         size_t pos = 0;
         while (pos < lc.pairs.size()) {
             // ---- chunk of pairs whose tie-bit rows fit the scratch budget ----
             std::vector<uint32_t> work;
             std::vector<uint64_t> sc_off;
+            std::vector<int32_t> kmin, kmax, rw, llcs;
             uint64_t used = 0;
             while (pos < lc.pairs.size()) {
                 const uint32_t pid = lc.pairs[pos];
-                const uint64_t need = ((uint64_t)b->b_len[pid] + 1ull) * 2ull * NLtot;
+                const int64_t m = b->a_len[pid], n = b->b_len[pid], D = dist[pid];
+                int32_t lo = -(1 << 30), hi = 1 << 30, groups = 1 << lc.logL;
+                if (lc.band) {
+                    const int64_t delta = n - m;
+                    lo = (int32_t)(-((D - delta) / 2) - 1);
+                    hi = (int32_t)((D + delta) / 2 + 1);
+                    groups = (int32_t)(((int64_t)hi - lo) >> logG) + 2;
+                }
+                const uint64_t need = ((uint64_t)n + 1ull) * (uint64_t)groups * 2ull * NL;
                 if (!work.empty() && used + need > budget_dwords) break;
                 if (need > budget_dwords) {
                     malcs_set_error("pair %u needs %llu MiB of tie-bit rows; device has %llu MiB free", pid,
@@ -308,22 +344,29 @@ static int graph_batch(malcs_batch *b, const int64_t *shift, const int64_t *max_
                     return MALCS_ERR_NOMEM;
                 }
                 work.push_back(pid); sc_off.push_back(used); used += need; pos++;
+                kmin.push_back(lo); kmax.push_back(hi); rw.push_back(groups);
+                llcs.push_back((int32_t)((m + n - D) / 2));
             }
             const uint32_t cnt = (uint32_t)work.size();
             if (d_work.alloc(cnt) || d_scoff.alloc(cnt) || d_scratch.alloc(used) || d_skip.alloc(cnt) ||
-                d_evcap.alloc(cnt) || d_evcnt.alloc(cnt) || d_evoff.alloc(cnt) || d_outoff.alloc(cnt)) {
+                d_evcap.alloc(cnt) || d_evcnt.alloc(cnt) || d_evoff.alloc(cnt) || d_outoff.alloc(cnt) ||
+                d_kmin.alloc(cnt) || d_kmax.alloc(cnt) || d_rw.alloc(cnt) || d_llcs.alloc(cnt) || d_fdist.alloc(cnt)) {
                 malcs_set_error("device allocation failed (chunk of %u pairs, %llu MiB of tie-bit rows)", cnt, (unsigned long long)(used >> 18));
                 return MALCS_ERR_NOMEM;
             }
             MALCS_HIP(hipMemcpyAsync(d_work.p, work.data(), cnt * 4ull, hipMemcpyHostToDevice, st));
             MALCS_HIP(hipMemcpyAsync(d_scoff.p, sc_off.data(), cnt * 8ull, hipMemcpyHostToDevice, st));
+            MALCS_HIP(hipMemcpyAsync(d_kmin.p, kmin.data(), cnt * 4ull, hipMemcpyHostToDevice, st));
+            MALCS_HIP(hipMemcpyAsync(d_kmax.p, kmax.data(), cnt * 4ull, hipMemcpyHostToDevice, st));
+            MALCS_HIP(hipMemcpyAsync(d_rw.p, rw.data(), cnt * 4ull, hipMemcpyHostToDevice, st));
+            MALCS_HIP(hipMemcpyAsync(d_llcs.p, llcs.data(), cnt * 4ull, hipMemcpyHostToDevice, st));
             MALCS_HIP(hipEventRecord(ctx->ev0, st));
-            int rc = malcs_graph_launch_forward(b, lc.W, lc.logL, d_work.p, cnt, d_scratch.p, d_scoff.p, b->d_dist);
+            int rc = malcs_graph_launch_forward(b, lc.W, lc.logL, lc.band, d_work.p, cnt, d_scratch.p, d_scoff.p,
+                                                d_kmin.p, d_kmax.p, d_rw.p, d_fdist.p);
             if (rc) return rc;
             MALCS_HIP(hipEventRecord(ctx->ev1, st));
-            // distances of the chunk (scattered in d_dist by pair id): fetch the whole array once per chunk
-            std::vector<int32_t> dist(N);
-            MALCS_HIP(hipMemcpyAsync(dist.data(), b->d_dist, N * 4ull, hipMemcpyDeviceToHost, st));
+            std::vector<int32_t> fdist(cnt);
+            MALCS_HIP(hipMemcpyAsync(fdist.data(), d_fdist.p, cnt * 4ull, hipMemcpyDeviceToHost, st));
             MALCS_HIP(hipStreamSynchronize(st));
             float ms = 0;
             MALCS_HIP(hipEventElapsedTime(&ms, ctx->ev0, ctx->ev1));
@@ -335,11 +378,12 @@ static int graph_batch(malcs_batch *b, const int64_t *shift, const int64_t *max_
             uint64_t ev_total = 0;
             for (uint32_t s = 0; s < cnt; s++) {
                 const uint32_t pid = work[s];
-                pair_graph &G = out->g[pid];
-                G.distance = dist[pid];
-                const int64_t md = max_distance ? max_distance[pid] : 0;
-                if (md && G.distance > md) { skip[s] = 1; G.status = MALCS_PAIR_MAX_DISTANCE_EXCEEDED; }
-                ev_cap[s] = skip[s] ? 0u : 64u + 16u * (uint32_t)G.distance;
+                if (fdist[s] != dist[pid]) {
+                    malcs_set_error("pair %u: forward pass found distance %d inside the band, expected %d (internal error)",
+                                    pid, fdist[s], dist[pid]);
+                    return MALCS_ERR_INTERNAL;
+                }
+                ev_cap[s] = 64u + 16u * (uint32_t)dist[pid];
                 ev_off[s] = ev_total;
                 ev_total += ev_cap[s];
             }
@@ -350,8 +394,8 @@ static int graph_batch(malcs_batch *b, const int64_t *shift, const int64_t *max_
                 MALCS_HIP(hipMemcpyAsync(d_evoff.p, ev_off.data(), cnt * 8ull, hipMemcpyHostToDevice, st));
                 MALCS_HIP(hipMemsetAsync(d_evcnt.p, 0, cnt * 4ull, st));
                 MALCS_HIP(hipEventRecord(ctx->ev1, st));
-                rc = malcs_graph_launch_reach(b, lc.W, lc.logL, d_work.p, cnt, d_scratch.p, d_scoff.p, d_skip.p,
-                                              d_events.p, d_evoff.p, d_evcap.p, d_evcnt.p);
+                rc = malcs_graph_launch_reach(b, lc.W, lc.logL, lc.band, d_work.p, cnt, d_scratch.p, d_scoff.p, d_kmin.p,
+                                              d_kmax.p, d_rw.p, d_llcs.p, d_skip.p, d_events.p, d_evoff.p, d_evcap.p, d_evcnt.p);
                 if (rc) return rc;
                 MALCS_HIP(hipEventRecord(ctx->ev2, st));
                 std::vector<uint32_t> ev_cnt(cnt);

@@ -23,75 +23,12 @@
 //
 // Algorithmic work: 4 dword ops per 32 cells for DNA = 0.125 lane-op per cell.
 #include "malcs_internal.hpp"
+#include "malcs_device.hpp"
 #include <algorithm>
 
 namespace {
 
-// One limb of one column: U = V & Match (NP v_bitop3_b32, the match mask never materialises),
-// S = V + U + carry (v_addc_co_u32 with the carry in an SGPR pair, so that it can be handed from limb
-// to limb, from lane to lane and from step to step without touching VALU registers).
-// The two v_bitop3 in front of every v_addc also provide the wait states gfx950 needs between a VALU
-// write of an SGPR and a VALU read of it, which the compiler cannot see inside inline asm.
-template <int NP, bool MASKED> struct limb;
-
-template <> struct limb<2, false> {
-    static __device__ __forceinline__ void step(uint32_t &U, uint32_t &S, uint64_t &cout, uint32_t V, uint64_t cin, uint32_t,
-                                                const uint32_t *P, const uint32_t *x)
-    {
-        asm("v_bitop3_b32 %0, %3, %5, %6 bitop3:0x90\n\tv_bitop3_b32 %0, %0, %7, %8 bitop3:0x90\n\t"
-            "v_addc_co_u32_e64 %1, %2, %3, %0, %4"
-            : "=&v"(U), "=&v"(S), "=&s"(cout) : "v"(V), "s"(cin), "v"(P[0]), "v"(x[0]), "v"(P[1]), "v"(x[1]));
-    }
-};
-template <> struct limb<2, true> {
-    static __device__ __forceinline__ void step(uint32_t &U, uint32_t &S, uint64_t &cout, uint32_t V, uint64_t cin, uint32_t act,
-                                                const uint32_t *P, const uint32_t *x)
-    {
-        asm("v_bitop3_b32 %0, %3, %6, %7 bitop3:0x90\n\tv_bitop3_b32 %0, %0, %8, %9 bitop3:0x90\n\t"
-            "v_and_b32 %0, %0, %5\n\tv_addc_co_u32_e64 %1, %2, %3, %0, %4"
-            : "=&v"(U), "=&v"(S), "=&s"(cout) : "v"(V), "s"(cin), "v"(act), "v"(P[0]), "v"(x[0]), "v"(P[1]), "v"(x[1]));
-    }
-};
-// generic plane counts: the match mask is folded plane by plane in C (the compiler emits v_bitop3),
-// only the carry-chained addition is asm; s_nop 1 supplies the wait states
-template <int NP, bool MASKED> struct limb {
-    static __device__ __forceinline__ void step(uint32_t &U, uint32_t &S, uint64_t &cout, uint32_t V, uint64_t cin, uint32_t act,
-                                                const uint32_t *P, const uint32_t *x)
-    {
-        uint32_t u = V;
-#pragma unroll
-        for (int p = 0; p < NP; p++) u &= ~(P[p] ^ x[p]);
-        if (MASKED) u &= act;
-        U = u;
-        asm("s_nop 1\n\tv_addc_co_u32_e64 %0, %1, %2, %3, %4" : "=v"(S), "=&s"(cout) : "v"(V), "v"(u), "s"(cin));
-    }
-};
-
-// carry out of every lane -> carry into the next lane of the same pair (scalar unit, lane masks).
-// Written as asm so that the value provably stays in SGPRs between the v_addc of one step and the next.
-__device__ __forceinline__ uint64_t carry_to_next_lane(uint64_t cout, uint64_t segmask)
-{
-    uint64_t cin;
-    asm("s_lshl_b64 %0, %1, 1\n\ts_and_b64 %0, %0, %2" : "=&s"(cin) : "s"(cout), "s"(segmask) : "scc");
-    return cin;
-}
-
-// One column for one lane: chain the limbs, return the carry out of the lane's top limb.
-template <int NL, int NP, bool MASKED>
-__device__ __forceinline__ uint64_t column_step(uint32_t (&V)[NL], const uint32_t (&P)[NL][NP],
-                                                const uint32_t (&x)[NP], uint32_t act, uint64_t cin)
-{
-    uint64_t c = cin;
-#pragma unroll
-    for (int k = 0; k < NL; k++) {
-        uint32_t U, S;
-        uint64_t co;
-        limb<NP, MASKED>::step(U, S, co, V[k], c, act, P[k], x);
-        V[k] = S | (V[k] ^ U);
-        c = co;
-    }
-    return c;
-}
+using namespace malcs_dev;
 
 // The lanes of a pair work as a systolic array: lane q handles text column (step - q), so the carry
 // that leaves lane q-1 in one step is exactly the carry lane q needs in the next step.  It travels
@@ -215,13 +152,6 @@ k_llcs_bitpar(const uint32_t *__restrict__ planes,
 // enters in lane 63.  Freezing a group and starting a group late both restrict the DP to paths that
 // stay inside the window, so the result D' is exact whenever D' <= T (then no alignment of cost <= D'
 // leaves the band); the host retries with a wider window otherwise.
-__device__ __forceinline__ uint64_t carry_window_down(uint64_t cin)
-{
-    uint64_t out;
-    asm("s_lshr_b64 %0, %1, 1" : "=s"(out) : "s"(cin) : "scc");
-    return out;
-}
-
 template <int W, int NP>
 __global__ void __launch_bounds__(64)
 k_llcs_band(const uint32_t *__restrict__ planes,

@@ -279,9 +279,10 @@ def test_from_variant_and_from_supremal(native):
         assert graph_record(graph) == rec["graph"]
 
 
-@pytest.mark.parametrize("idx", [i for i, r in enumerate(LARGE["from_sequence"]) if r["len_reference"] <= 16000])
+@pytest.mark.parametrize("idx", range(len(LARGE["from_sequence"])))
 def test_large_from_sequence(native, idx):
-    """BASELINE config 3 shape: 10 kb windows, full graph, hash of the canonical record."""
+    """BASELINE configs 3 and 5 (i): 10 kb tandem-repeat windows, 100 kb and 1 Mb sparse pairs; full graph,
+    SHA-256 of the canonical record captured from the reference."""
     from algebra_amd.lcs import LCSgraph
     rec = LARGE["from_sequence"][idx]
     a, b = gen.large_pair(rec["case"])
@@ -296,6 +297,29 @@ def test_large_from_sequence(native, idx):
 
 def test_graph_size_limit_is_loud(native):
     from algebra_amd.lcs import LCSgraph
-    a = "ACGT" * 5000
-    with pytest.raises(native.MalcsError, match="exceeds"):
-        LCSgraph(a, a[:-1])
+    rs = np.random.RandomState(9)
+    a, b = gen.random_seq(rs, 60000), gen.random_seq(rs, 60000)      # ~42 000 edits: wider than any band
+    with pytest.raises(native.MalcsError, match="exceed"):
+        LCSgraph(a, b)
+
+
+def test_graph_band_vs_oracle(native):
+    """Windows beyond 4 095 symbols run the sliding-window kernels: all band widths, both signs of n - m."""
+    from oracle import oracle as O
+    from algebra_amd.lcs.encoding import encode_pairs
+    rs = np.random.RandomState(21)
+    pairs = []
+    for m, p in ((4096, 0.002), (5000, 0.01), (8000, 0.05), (12000, 0.1), (9000, 0.3), (20000, 0.004)):
+        a = gen.random_seq(rs, m)
+        pairs.append((a, gen.mutate(rs, a, p, p)))
+    a = gen.random_seq(rs, 7000)
+    pairs += [(a, a[:3000] + a[3500:]), (a[:2000] + a[2600:], a), (a, a), tuple(gen.tandem_pair(rs, 9000, 12))]
+    syms, a_off, a_len, b_off, b_len, n_symbols = encode_pairs(pairs)
+    batch = native.Batch(native.default_context(), syms, a_off, a_len, b_off, b_len, n_symbols)
+    res = batch.graphs(np.arange(len(pairs), dtype=np.int64))
+    batch.close()
+    for i, (a, b) in enumerate(pairs):
+        ref = O.lcs_graph(a, b, i)
+        assert res.distance[i] == ref.distance and tuple(res.supremal[i]) == ref.supremal, i
+        assert np.array_equal(res.nodes(i), ref.nodes) and np.array_equal(res.edges(i), ref.edges), i
+    res.close()

@@ -105,9 +105,9 @@ def test_extract_like_the_reference_tests():
     assert variants2 == variants
 
 
-@pytest.mark.parametrize("idx", [i for i, r in enumerate(LARGE["from_sequence"]) if r["len_reference"] <= 16000])
-def test_extract_sequence_10kb(idx):
-    """BASELINE config 3: extract_sequence on 10 kb windows with tandem-repeat indels."""
+@pytest.mark.parametrize("idx", range(len(LARGE["from_sequence"])))
+def test_extract_sequence_large(idx):
+    """BASELINE configs 3 and 5 (i): extract_sequence on 10 kb tandem-repeat windows and on 100 kb / 1 Mb pairs."""
     from algebra_amd.extractor import extract_sequence, to_hgvs
     rec = LARGE["from_sequence"][idx]
     a, b = gen.large_pair(rec["case"])
