@@ -147,6 +147,50 @@ class LCSgraph:
                 return graph
             offset *= 2
 
+    @classmethod
+    def from_variant_batch(cls, reference, alleles, offset=10, ctx=None):
+        """`[from_variant(reference, allele, offset) for allele in alleles]` with the windows of every
+        widening round built in one device batch (reference lcs_graph.py:113-123 runs the rounds per
+        allele; alleles are independent, so the rounds can be shared)."""
+        results = [None] * len(alleles)
+        pending = []                                   # (index, delins Variant, offset)
+        trivial = []
+        for idx, variants in enumerate(alleles):
+            if not variants:
+                trivial.append(idx)
+                continue
+            start = min(v.start for v in variants)
+            end = max(v.end for v in variants)
+            observed = patch(reference[start:end], [Variant(v.start - start, v.end - start, v.sequence) for v in variants])
+            if reference[start:end] == observed:
+                trivial.append(idx)
+                continue
+            allele = Variant(start, end, observed)
+            pending.append((idx, allele, max(offset, len(allele) // 2, 1)))
+        if trivial:
+            empty = cls.batch([("", "")], ctx=ctx)[0]
+            for idx in trivial:
+                results[idx] = empty
+        while pending:
+            windows, shifts, bounds = [], [], []
+            for _, allele, off in pending:
+                lo = max(0, allele.start - off)
+                hi = min(len(reference), allele.end + off)
+                windows.append((reference[lo:hi], reference[lo:allele.start] + allele.sequence + reference[allele.end:hi]))
+                shifts.append(lo)
+                bounds.append((lo, hi))
+            graphs = cls.batch(windows, shifts, ctx=ctx)
+            again = []
+            for (idx, allele, off), graph, (lo, hi) in zip(pending, graphs, bounds):
+                inside_left = graph.supremal.start > lo or graph.supremal.start == 0
+                inside_right = graph.supremal.end < hi or graph.supremal.end == len(reference)
+                if inside_left and inside_right:
+                    results[idx] = graph
+                else:
+                    again.append((idx, allele, off * 2))
+            pending = again
+        return results
+
     def bfs_traversal(self, atomics=False):
         """Generate all (source node, sink node, [variants]) edges in BFS order
         (reference lcs_graph.py:125-160; nodes compare by value, as there)."""

@@ -76,6 +76,22 @@ def test_compare_matrix(tile):
         assert stats["dp_pairs"] > 0
 
 
+def test_from_variant_batch_equals_singles():
+    from algebra_amd.lcs import LCSgraph
+    from algebra_amd.variants import Variant
+    from util import graph_record
+    case = SEQS["matrices"][1]
+    alleles = [[Variant(*v)] for v in case["variants"]] + [[], [Variant(3, 4, case["reference"][3])]]
+    alleles.append([Variant(5, 6, "T" if case["reference"][5] != "T" else "G"), Variant(40, 42, "")])
+    batch = LCSgraph.from_variant_batch(case["reference"], alleles, offset=2)
+    for allele, got in zip(alleles, batch):
+        assert graph_record(got) == graph_record(LCSgraph.from_variant(case["reference"], allele, offset=2))
+    assert [[g.supremal.start, g.supremal.end, g.supremal.sequence] for g in batch[:len(case["supremals"])]] == case["supremals"]
+    for rec in REF["from_variant"]:
+        got = LCSgraph.from_variant_batch(rec["reference"], [[Variant(*v) for v in rec["variants"]]], rec["offset"])[0]
+        assert graph_record(got) == rec["graph"]
+
+
 def test_extract_sequence_canonical_and_hgvs():
     from algebra_amd.extractor import extract_sequence, to_hgvs
     for rec in REF["sequences"] + SEQS["sequences"]:
