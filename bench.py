@@ -68,7 +68,7 @@ def cpu_baseline(data, cells_per_pair, budget_s=12.0):
             passes += 1
         wall = time.perf_counter() - t0
         # the reference's own flavour: interpreted Python, one process per core, smaller sample
-        py_n = min(n, 512 * cores)
+        py_n = min(n, 4096 * cores)
         pb = np.linspace(0, py_n, cores + 1).astype(int)
         t1 = time.perf_counter()
         pool.map(_python_pass, [(int(pb[i]), int(pb[i + 1])) for i in range(cores)])
@@ -85,6 +85,39 @@ def cpu_baseline(data, cells_per_pair, budget_s=12.0):
     }
 
 
+def extra_configs(ctx, _native, gen):
+    """Secondary figures beside the headline (not the timed region): kernel family 2 on the C2 batch shape
+    and the C4 relation matrix, both end to end from host buffers."""
+    out = {}
+    n = 20000
+    batch = _native.Batch(ctx, *gen.c2_batch(n, seed=12), 4)
+    batch.graphs().close()                                     # warm-up
+    t0 = time.perf_counter()
+    g = batch.graphs()
+    wall = time.perf_counter() - t0
+    out["c2_lcs_graphs"] = {"pairs": n, "graphs_per_s": round(n / wall, 1), "forward_ms": round(float(g.timing[0]), 3),
+                            "reach_ms": round(float(g.timing[1]), 3), "host_build_ms": round(float(g.timing[2]), 1),
+                            "tie_bit_GB_per_s": {"forward_write": round(n * 1e6 * 0.25 / (float(g.timing[0]) * 1e-3) / 1e9, 1),
+                                                 "reach_read": round(n * 1e6 * 0.25 / (float(g.timing[1]) * 1e-3) / 1e9, 1)}}
+    g.close()
+    batch.close()
+    from algebra_amd.lcs import LCSgraph
+    from algebra_amd.relations import compare_matrix
+    from algebra_amd.variants import Variant
+    case = gen.matrix_case(seed=4, length=100000, n_clusters=50, per_cluster=100, width=200)
+    t0 = time.perf_counter()
+    graphs = LCSgraph.from_variant_batch(case["reference"], [[Variant(*v)] for v in case["variants"]], ctx=ctx)
+    t1 = time.perf_counter()
+    stats = {}
+    compare_matrix(case["reference"], graphs, stats=stats)
+    t2 = time.perf_counter()
+    pairs = len(graphs) * (len(graphs) - 1) // 2
+    out["c4_relation_matrix"] = {"variants": len(graphs), "pairs": pairs, "relations_per_s": round(pairs / (t2 - t1), 1),
+                                 "pairs_reaching_dp": stats["dp_pairs"], "supremal_graphs_s": round(t1 - t0, 3),
+                                 "matrix_s": round(t2 - t1, 3)}
+    return out
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -92,6 +125,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--pairs", type=int, default=100000)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-extra", action="store_true", help="skip the secondary configs (graphs, relation matrix)")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -173,9 +207,11 @@ def main():
             "mean_distance": round(mean_distance, 3),
             "roofline": {"bound": "valu", "achieved": round(achieved, 2), "peak": round(PEAK_LANE_OPS / 1e12, 1),
                          "unit": "T int32 lane-op/s", "frac": round(achieved * 1e12 / PEAK_LANE_OPS, 4),
-                         "traffic": traffic, "kernel": "k_llcs_bitpar<4,2>", "kernel_ms": round(kernel_ms, 4),
+                         "traffic": traffic, "kernel": "k_llcs_bitpar<4,2,true>", "kernel_ms": round(kernel_ms, 4),
                          "algorithmic": f"{OPS_PER_CELL} lane-op/cell x {cells:.4g} cells/launch"},
         }
+        if world == 1 and not args.no_extra:
+            out["extra"] = extra_configs(ctx, _native, gen)
         if not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(data, cells / args.pairs)
         print(json.dumps(out), flush=True)
