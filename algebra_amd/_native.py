@@ -56,6 +56,8 @@ def _load():
         "malcs_graphs_runs": (c.c_int, [vp, u64, vp]),
         "malcs_graphs_nodes": (c.c_int, [vp, u64, vp]),
         "malcs_graphs_edges": (c.c_int, [vp, u64, vp]),
+        "malcs_graphs_canonical_count": (c.c_int, [vp, u64, P(i64)]),
+        "malcs_graphs_canonical": (c.c_int, [vp, u64, vp]),
         "malcs_graphs_timing": (c.c_int, [vp, vp]),
     }
     for name, (res, args) in sig.items():
@@ -230,6 +232,13 @@ class Graphs:
     def edges(self, i):
         out = np.zeros((int(self.counts[i, 3]), 6), dtype=np.int64)
         check(lib.malcs_graphs_edges(self.handle, i, ptr(out)))
+        return out
+
+    def canonical(self, i):
+        n = ctypes.c_int64()
+        check(lib.malcs_graphs_canonical_count(self.handle, i, ctypes.byref(n)))
+        out = np.zeros((n.value, 4), dtype=np.int64)
+        check(lib.malcs_graphs_canonical(self.handle, i, ptr(out)))
         return out
 
     def close(self):

@@ -42,6 +42,8 @@ struct pair_graph {
     std::vector<int64_t> runs;      // 4 per run (shifted row, col; length; level)
     std::vector<int64_t> nodes;     // 3 per node
     std::vector<int64_t> edges;     // 6 per edge
+    std::vector<int64_t> canon;     // 4 per canonical variant (start, end, obs_from, obs_to), filled on demand
+    bool canon_done = false;
 };
 
 // ---- events -> runs in the reference's emission order -------------------------------------------
@@ -220,6 +222,115 @@ void build_graph(int64_t m, int64_t n, int64_t shift, const std::vector<run> &ru
             int64_t *o = &G.edges[6 * ei++];
             o[0] = (int64_t)h; o[1] = id[e.child]; o[2] = e.start; o[3] = e.end; o[4] = e.from; o[5] = e.to;
         }
+    }
+}
+
+// ---- canonical allele ---------------------------------------------------------------------------
+// Restatement of the reference's canonical() (algebra/extractor/extractor.py:10-89) on the node / edge
+// arrays: BFS from the source; a node reached again at the same depth merges the two ways in into one
+// delins up to their lowest common ancestor; finally walk back from the sink.  Nodes are keyed by value
+// (row, col, length), as the reference's dict does.
+struct cvar { int64_t start, end, from, to; };      // variant; sequence = supremal.sequence[from:to] or window slice (see below)
+
+void canonical_of(pair_graph &G)
+{
+    const size_t nn = G.nodes.size() / 3, ne = G.edges.size() / 6;
+    G.canon.clear();
+    G.canon_done = true;
+    if (nn == 0) return;
+    // CSR over edges (already grouped by source in node order)
+    std::vector<size_t> first(nn + 1, 0);
+    for (size_t e = 0; e < ne; e++) first[(size_t)G.edges[6 * e] + 1]++;
+    for (size_t v = 0; v < nn; v++) first[v + 1] += first[v];
+    // value -> representative id
+    std::vector<int32_t> rep(nn);
+    {
+        std::vector<int32_t> order(nn);
+        for (size_t v = 0; v < nn; v++) order[v] = (int32_t)v;
+        auto key_less = [&](int32_t a, int32_t b) {
+            for (int k = 0; k < 3; k++) if (G.nodes[3 * a + k] != G.nodes[3 * b + k]) return G.nodes[3 * a + k] < G.nodes[3 * b + k];
+            return a < b;
+        };
+        std::sort(order.begin(), order.end(), key_less);
+        for (size_t i = 0; i < nn; i++) {
+            const int32_t v = order[i];
+            const bool same = i && G.nodes[3 * order[i - 1]] == G.nodes[3 * v] && G.nodes[3 * order[i - 1] + 1] == G.nodes[3 * v + 1] &&
+                              G.nodes[3 * order[i - 1] + 2] == G.nodes[3 * v + 2];
+            rep[v] = same ? rep[order[i - 1]] : v;
+        }
+    }
+    const int64_t shift = G.nodes[0];                        // source.row
+    const int64_t sup_from = G.supremal[2], sup_to = G.supremal[3];
+    auto row = [&](int32_t v) { return G.nodes[3 * v]; };
+    auto col = [&](int32_t v) { return G.nodes[3 * v + 1]; };
+    auto len = [&](int32_t v) { return G.nodes[3 * v + 2]; };
+    // slice of supremal.sequence -> slice of the observed window (Python slice clamping)
+    auto spelled = [&](int32_t anchor, int64_t start, int32_t target, int64_t end) -> cvar {
+        int64_t x = col(anchor) + start - row(anchor) - shift, y = col(target) + end - row(target) - shift;
+        const int64_t n = sup_to - sup_from;
+        x = std::max<int64_t>(0, std::min(x, n)); y = std::max<int64_t>(0, std::min(y, n));
+        if (y < x) y = x;
+        return {start, end, sup_from + x, sup_from + y};
+    };
+    struct way { int32_t parent; cvar edge; int64_t depth; bool has_edge; };
+    std::vector<way> best(nn);
+    std::vector<uint8_t> seen(nn, 0);
+    struct item { int32_t node, parent; cvar edge; int64_t depth; bool has_edge; };
+    std::vector<item> queue;
+    queue.push_back({0, -1, {0, 0, 0, 0}, 0, false});
+    int32_t sink = -1;
+    for (size_t head = 0; head < queue.size(); head++) {
+        const item it = queue[head];
+        const int32_t node = rep[it.node];
+        if (first[it.node + 1] == first[it.node]) sink = node;
+        if (!seen[node]) {
+            seen[node] = 1;
+            best[node] = {it.parent < 0 ? -1 : rep[it.parent], it.edge, it.depth, it.has_edge};
+            for (size_t e = first[it.node]; e < first[it.node + 1]; e++) {
+                const int64_t *x = &G.edges[6 * e];
+                queue.push_back({(int32_t)x[1], it.node, {x[2], x[3], x[4], x[5]}, it.depth + 1, true});
+            }
+            continue;
+        }
+        const way old = best[node];
+        if (it.depth > old.depth) continue;
+        // lowest common ancestor of the two ways in; the right-hand edge is not reset between outer rounds (:33-40)
+        int32_t left = old.parent, right = rep[it.parent];
+        cvar left_edge = old.edge, right_edge = it.edge;
+        int32_t ancestor = -1;
+        while (left >= 0 && ancestor < 0) {
+            int32_t probe = right;
+            while (probe >= 0) {
+                if (probe == left) { ancestor = left; break; }
+                right_edge = best[probe].edge;
+                probe = best[probe].parent;
+            }
+            if (ancestor >= 0) break;
+            left_edge = best[left].edge;
+            left = best[left].parent;
+        }
+        if (ancestor < 0) continue;                           // cannot happen on graphs built by build_graph
+        const int64_t start = std::min(left_edge.start, right_edge.start);
+        const int32_t parent = rep[it.parent];
+        if (old.parent != parent && row(old.parent) + len(old.parent) == row(parent) + len(parent) &&
+            col(old.parent) + len(old.parent) == col(parent) + len(parent)) {                         // :63-69
+            const int64_t end = std::max(best[parent].edge.end, best[old.parent].edge.end);
+            best[old.parent] = {ancestor, spelled(ancestor, start, parent, end), it.depth - 1, true};
+        } else {                                                                                   // :70-74
+            const int64_t end = std::max(old.edge.end, it.edge.end);
+            best[node] = {ancestor, spelled(ancestor, start, node, end), it.depth, true};
+        }
+    }
+    std::vector<cvar> back;
+    for (int32_t v = sink; v >= 0;) {                         // :82-89
+        const way &w = best[v];
+        if (w.parent < 0) break;
+        back.push_back(w.edge);
+        v = w.parent;
+    }
+    for (size_t i = back.size(); i-- > 0;) {
+        G.canon.push_back(back[i].start); G.canon.push_back(back[i].end);
+        G.canon.push_back(back[i].from); G.canon.push_back(back[i].to);
     }
 }
 
@@ -531,6 +642,25 @@ int malcs_graphs_supremal(const malcs_graphs *g, int64_t *supremal4)
 int malcs_graphs_runs(const malcs_graphs *g, uint64_t i, int64_t *dst) { MALCS_COPY_OUT(runs) }
 int malcs_graphs_nodes(const malcs_graphs *g, uint64_t i, int64_t *dst) { MALCS_COPY_OUT(nodes) }
 int malcs_graphs_edges(const malcs_graphs *g, uint64_t i, int64_t *dst) { MALCS_COPY_OUT(edges) }
+
+int malcs_graphs_canonical_count(malcs_graphs *g, uint64_t i, int64_t *count)
+{
+    if (!g || i >= g->g.size() || !count) { malcs_set_error("bad argument"); return MALCS_ERR_ARG; }
+    if (g->g[i].status != MALCS_PAIR_OK) { malcs_set_error("pair %llu has no graph", (unsigned long long)i); return MALCS_ERR_ARG; }
+    if (!g->g[i].canon_done) canonical_of(g->g[i]);
+    *count = (int64_t)g->g[i].canon.size() / 4;
+    return MALCS_OK;
+}
+
+int malcs_graphs_canonical(malcs_graphs *g, uint64_t i, int64_t *dst)
+{
+    int64_t n = 0;
+    int rc = malcs_graphs_canonical_count(g, i, &n);
+    if (rc) return rc;
+    if (n && !dst) { malcs_set_error("bad argument"); return MALCS_ERR_ARG; }
+    if (n) memcpy(dst, g->g[i].canon.data(), (size_t)n * 4 * sizeof(int64_t));
+    return MALCS_OK;
+}
 
 int malcs_graphs_timing(const malcs_graphs *g, float *out3)
 {

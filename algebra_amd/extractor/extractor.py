@@ -3,8 +3,10 @@
 Host-side restatement of the reference's `algebra/extractor/extractor.py`: `canonical()`
 (:10-89, a BFS over the graph that merges equally short alternatives into one delins up to their
 lowest common ancestor) and the repeat-aware `to_hgvs()` (:138-228).  The graphs come from
-`algebra_amd.lcs.LCSgraph` (kernel family 2); everything here is pointer chasing over O(d) nodes
-and string formatting.
+`algebra_amd.lcs.LCSgraph` (kernel family 2).  For those graphs `canonical()` runs inside the
+library on the node / edge arrays (malcs_build.cpp, same procedure) so that a 10 kb tandem-repeat
+graph with 400 k edges never has to become Python objects; the Python body below serves graphs
+that were put together by hand and documents the procedure.
 """
 
 from collections import deque
@@ -18,6 +20,12 @@ def canonical(graph):
 
     `best[node]` is (parent, edge into node, depth) of the first/merged shortest way to reach
     `node`; nodes are keyed by value, as in the reference."""
+    arrays = graph._canonical_arrays() if hasattr(graph, "_canonical_arrays") else None
+    if arrays is not None:
+        # the library ran the same procedure on its node / edge arrays (malcs_graphs_canonical)
+        window = graph._observed
+        return [Variant(start, end, window[lo:hi]) for start, end, lo, hi in arrays.tolist()]
+
     observed = graph.supremal.sequence
     source = graph._source
     shift = source.row

@@ -54,21 +54,53 @@ class LCSgraph:
 
     def __init__(self, reference, observed, shift=0, max_distance=None):
         built = LCSgraph.batch([(reference, observed)], [shift], [max_distance])[0]
-        self.distance = built.distance
-        self.supremal = built.supremal
-        self._source = built._source
+        self.__dict__.update(built.__dict__)
+
+    # `_source` (reference lcs_graph.py:61) is materialised on first use: the library keeps nodes and
+    # edges as arrays, and callers such as the extractor or the relation matrix often never walk them.
+    @property
+    def _source(self):
+        source = self.__dict__.get("_built_source")
+        if source is None:
+            source = self._materialise()
+        return source
+
+    @_source.setter
+    def _source(self, node):
+        self.__dict__["_built_source"] = node
+
+    def _materialise(self):
+        observed = self._observed
+        if self._result is not None:
+            result, index = self._result
+            nodes, edges = result.nodes(index), result.edges(index)
+        else:
+            nodes, edges = self._arrays
+        made = [LCSgraph.Node(int(r), int(c), int(length)) for r, c, length in nodes.tolist()]
+        for src, dst, v_start, v_end, v_lo, v_hi in edges.tolist():
+            made[src].edges.append((made[dst], Variant(v_start, v_end, observed[v_lo:v_hi])))
+        self.__dict__["_built_source"] = made[0]
+        return made[0]
 
     @classmethod
-    def _from_arrays(cls, observed, distance, supremal, nodes, edges):
+    def _from_arrays(cls, observed, distance, supremal, nodes=None, edges=None, result=None):
+        """Graph over the arrays of one pair: either explicit `nodes`/`edges`, or `result` =
+        (Graphs handle, pair index) to fetch them from on demand."""
         self = cls.__new__(cls)
         self.distance = int(distance)
         start, end, lo, hi = (int(x) for x in supremal)
         self.supremal = Variant(start, end, observed[lo:hi])
-        made = [cls.Node(int(r), int(c), int(length)) for r, c, length in nodes.tolist()]
-        for src, dst, v_start, v_end, v_lo, v_hi in edges.tolist():
-            made[src].edges.append((made[dst], Variant(v_start, v_end, observed[v_lo:v_hi])))
-        self._source = made[0]
+        self._observed = observed
+        self._result = result
+        self._arrays = (nodes, edges)
         return self
+
+    def _canonical_arrays(self):
+        """Canonical allele computed by the library on its arrays, or None for hand-built graphs."""
+        if self.__dict__.get("_result") is None:
+            return None
+        result, index = self._result
+        return result.canonical(index)
 
     @classmethod
     def batch(cls, pairs, shifts=None, max_distances=None, ctx=None):
@@ -91,13 +123,11 @@ class LCSgraph:
             res = batch.graphs(shift, limit)
         finally:
             batch.close()
-        try:
-            if np.any(res.status == _native.PAIR_MAX_DISTANCE_EXCEEDED):
-                raise ValueError("maximum distance exceeded")
-            return [cls._from_arrays(pairs[i][1], res.distance[i], res.supremal[i], res.nodes(i), res.edges(i))
-                    for i in range(n)]
-        finally:
+        if np.any(res.status == _native.PAIR_MAX_DISTANCE_EXCEEDED):
             res.close()
+            raise ValueError("maximum distance exceeded")
+        # the graphs share the result handle; it is released when the last of them goes away
+        return [cls._from_arrays(pairs[i][1], res.distance[i], res.supremal[i], result=(res, i)) for i in range(n)]
 
     @classmethod
     def from_sequence(cls, reference, observed):

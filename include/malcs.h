@@ -122,6 +122,11 @@ int malcs_graphs_supremal(const malcs_graphs *graphs, int64_t *supremal4);
 int malcs_graphs_runs(const malcs_graphs *graphs, uint64_t i, int64_t *runs4);
 int malcs_graphs_nodes(const malcs_graphs *graphs, uint64_t i, int64_t *nodes3);
 int malcs_graphs_edges(const malcs_graphs *graphs, uint64_t i, int64_t *edges6);
+/* Canonical allele of pair i -- stands in for canonical(graph) (algebra/extractor/extractor.py:10-89): BFS over
+ * the graph, equally short alternatives merged into one delins up to their lowest common ancestor.
+ * count = number of variants; each is {start, end, obs_from, obs_to}: Variant(start, end, observed[obs_from:obs_to]). */
+int malcs_graphs_canonical_count(malcs_graphs *graphs, uint64_t i, int64_t *count);
+int malcs_graphs_canonical(malcs_graphs *graphs, uint64_t i, int64_t *variants4);
 /* timing split of the last malcs_lcs_graph_batch on this handle, milliseconds:
  * out[0] forward DP kernel, out[1] reach/extract kernel (HIP events), out[2] D2H + host graph build */
 int malcs_graphs_timing(const malcs_graphs *graphs, float *out3);

@@ -109,6 +109,19 @@ def test_extract_sequence_canonical_and_hgvs():
             assert [type(exc.value).__name__, str(exc.value)] == rec["hgvs_error"]
 
 
+def test_library_canonical_equals_python_canonical():
+    """malcs_graphs_canonical (C++ on arrays) against the Python body of extractor.canonical on the same graphs."""
+    from algebra_amd.extractor import canonical
+    from algebra_amd.lcs import LCSgraph
+    recs = REF["sequences"] + SEQS["sequences"]
+    graphs = LCSgraph.batch([(r["reference"], r["observed"]) for r in recs])
+    for rec, graph in zip(recs, graphs):
+        fast = canonical(graph)
+        graph._source                      # materialise, then hide the handle: forces the Python body
+        graph._result = None
+        assert canonical(graph) == fast, (rec["reference"], rec["observed"])
+
+
 def test_extract_like_the_reference_tests():
     from algebra_amd.extractor import extract, extract_sequence, extract_supremal, to_hgvs
     from algebra_amd.variants import Variant

@@ -20,6 +20,7 @@ def facade_graph_from_record(observed_unused, rec):
     self = LCSgraph.__new__(LCSgraph)
     self.distance = rec["distance"]
     self.supremal = Variant(*rec["supremal"])
+    self._result = None
     made = [LCSgraph.Node(*n) for n in rec["nodes"]]
     for src, dst, start, end, seq in rec["edges"]:
         made[src].edges.append((made[dst], Variant(start, end, seq)))
@@ -30,7 +31,7 @@ def facade_graph_from_record(observed_unused, rec):
 def oracle_graph(reference, observed, shift=0):
     from algebra_amd.lcs import LCSgraph
     g = O.lcs_graph(reference, observed, shift)
-    return LCSgraph._from_arrays(observed, g.distance, g.supremal, g.nodes, g.edges)
+    return LCSgraph._from_arrays(observed, g.distance, g.supremal, nodes=g.nodes, edges=g.edges)
 
 
 def test_canonical_and_hgvs_on_fixture_graphs():
