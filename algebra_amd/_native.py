@@ -47,6 +47,8 @@ def _load():
         "malcs_edit_distance_launch": (c.c_int, [vp]),
         "malcs_edit_distance_fetch": (c.c_int, [vp, vp]),
         "malcs_edit_distance_time": (c.c_int, [vp, c.c_int, P(c.c_float)]),
+        "malcs_edit_distance_time_kernel": (c.c_int, [vp, c.c_int, P(c.c_float)]),
+        "malcs_batch_plan_info": (c.c_int, [vp, P(c.c_uint64)]),
         "malcs_edit_distance_batch": (c.c_int, [vp, vp, u64, vp, vp, vp, vp, u64, c.c_int, vp]),
         "malcs_lcs_graph_batch": (c.c_int, [vp, vp, vp, P(vp)]),
         "malcs_graphs_destroy": (c.c_int, [vp]),
@@ -183,6 +185,17 @@ class Batch:
         ms = ctypes.c_float()
         check(lib.malcs_edit_distance_time(self.handle, int(iters), ctypes.byref(ms)))
         return ms.value
+
+    def time_dominant_kernel(self, iters):
+        ms = ctypes.c_float()
+        check(lib.malcs_edit_distance_time_kernel(self.handle, int(iters), ctypes.byref(ms)))
+        return ms.value
+
+    def plan_info(self):
+        info = (ctypes.c_uint64 * 6)()
+        check(lib.malcs_batch_plan_info(self.handle, info))
+        keys = ("window_pairs", "window_limbs", "window_threshold", "window_cells", "full_cells", "full_classes")
+        return dict(zip(keys, (int(x) for x in info)))
 
     def graphs(self, shift=None, max_distance=None):
         """LCSgraph(reference_i, observed_i, shift_i, max_distance_i) for every pair."""

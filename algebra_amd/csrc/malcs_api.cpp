@@ -102,6 +102,7 @@ static void batch_release(malcs_batch *b)
 {
     if (!b) return;
     hipSetDevice(b->ctx->device);
+    malcs_diag_release(b);
     hipFree(b->d_planes); hipFree(b->d_a_off); hipFree(b->d_a_len); hipFree(b->d_b_off); hipFree(b->d_b_len);
     hipFree(b->d_order); hipFree(b->d_dist);
     delete b;
@@ -242,6 +243,31 @@ int malcs_edit_distance_time(malcs_batch *b, int iters, float *ms_total)
     MALCS_HIP(hipEventRecord(c->ev1, c->stream));
     MALCS_HIP(hipEventSynchronize(c->ev1));
     MALCS_HIP(hipEventElapsedTime(ms_total, c->ev0, c->ev1));
+    return MALCS_OK;
+}
+
+int malcs_edit_distance_time_kernel(malcs_batch *b, int iters, float *ms_total)
+{
+    if (!b || !ms_total || iters < 1) { malcs_set_error("bad argument"); return MALCS_ERR_ARG; }
+    if (!b->diag.nlw) return malcs_edit_distance_time(b, iters, ms_total);
+    malcs_ctx *c = b->ctx;
+    MALCS_HIP(hipSetDevice(c->device));
+    MALCS_HIP(hipEventRecord(c->ev0, c->stream));
+    for (int i = 0; i < iters; i++) {
+        int rc = malcs_diag_launch(b, false);      // appends beyond a list's capacity are dropped by the kernel
+        if (rc) return rc;
+    }
+    MALCS_HIP(hipEventRecord(c->ev1, c->stream));
+    MALCS_HIP(hipEventSynchronize(c->ev1));
+    MALCS_HIP(hipEventElapsedTime(ms_total, c->ev0, c->ev1));
+    return MALCS_OK;
+}
+
+int malcs_batch_plan_info(const malcs_batch *b, uint64_t *info)
+{
+    if (!b || !info) { malcs_set_error("NULL argument"); return MALCS_ERR_ARG; }
+    info[0] = b->diag.n_pairs; info[1] = (uint64_t)b->diag.nlw; info[2] = (uint64_t)b->diag.T;
+    info[3] = b->diag.window_cells; info[4] = b->full_cells; info[5] = b->dist_buckets.size();
     return MALCS_OK;
 }
 

@@ -1,0 +1,499 @@
+// malcs_diag.hip -- kernel family 1, window class: distances of similar pairs from a few limbs around
+// the main diagonal.
+//
+// Stands in for edit_distance(a, b) (reference algebra/lcs/edit_distance.py:21-53).  The reference's
+// O(NP) sweep only visits the diagonals an alignment of cost <= D can reach; this is the bit-vector
+// counterpart: an alignment of cost <= T stays on diagonals k = col - row in
+// [-(T - delta)/2, delta + (T - delta)/2] (delta = n - m >= 0), so of every column only
+// T + 1 rows matter.  Rows are handled in limbs of 32; a window of NLW limbs that moves down one limb
+// per block of 32 columns covers all of them when T = 32 * NLW - 32.
+//
+//   * one LANE per pair, 64 pairs per wave, no cross-lane traffic at all: the window's limbs live in
+//     VGPRs (state V, pattern bit planes P), the carry chain of a column runs through the lane's own
+//     limbs (v_addc_co_u32 on SGPR-pair lane masks, as in malcs_dist.hip);
+//   * after 32 columns the lowest limb leaves the window (its zero bits are banked: they are that
+//     limb's share of the LLCS), the others move down one register, a fresh limb (V = all ones) enters
+//     on top.  Rows below the window keep what they had, rows above have not started: both restrict
+//     the DP to paths inside the window, so the result D' >= D, and D' == D whenever D' <= T
+//     (then no optimal alignment leaves the band);
+//   * pairs with D' > T are appended to a device-side list per full-matrix launch class and redone
+//     by k_llcs_bitpar_list (malcs_dist.hip) in the same launch sequence, no host round trip;
+//   * data layout: at plan time the pairs of the class are sorted by length and cut into tiles of 64;
+//     k_diag_layout writes, per tile, rows of 64 dwords (one per lane): 4 meta rows, the NLW-1 limbs
+//     the window starts with, then per block of columns the entering pattern limb and the 32 text
+//     bits of that block, already shifted to the lane's own diagonal offset.  The main loop therefore
+//     reads 2 * NP fully coalesced rows (1 KB for DNA) per 32 columns and wave and does no address
+//     arithmetic or funnel shifts of its own.
+//
+// Work per column and lane: NLW * (NP + 2) + NP VALU ops; for DNA and NLW = 3 that is 14 ops for what
+// the full-matrix kernel spends 4 * ceil(m / 32) + 2 on (130 for 1 kb).
+#include "malcs_internal.hpp"
+#include "malcs_device.hpp"
+#include <algorithm>
+#include <cstdlib>
+#include <utility>
+
+namespace {
+
+using namespace malcs_dev;
+
+constexpr int META_ROWS = 4;          // pid, m, n, kmax | retry class << 16
+
+__host__ __device__ inline int diag_first_limb(int kmax) { return -((kmax + 31) >> 5); }
+
+// ---- plan-time layout --------------------------------------------------------------------------
+// grid (rows of the longest tile, tiles), block 64: thread = (tile, row r, lane)
+template <int NP>
+__global__ void __launch_bounds__(64)
+k_diag_layout(const uint32_t *__restrict__ planes,
+              const uint32_t *__restrict__ a_off, const uint32_t *__restrict__ a_len,
+              const uint32_t *__restrict__ b_off, const uint32_t *__restrict__ b_len,
+              const uint32_t *__restrict__ tile_pid, const uint32_t *__restrict__ tile_kc,
+              const uint32_t *__restrict__ tile_off, const uint32_t *__restrict__ tile_iters,
+              int nlw, uint32_t *__restrict__ rows)
+{
+    const uint32_t tile = blockIdx.y, r = blockIdx.x, lane = threadIdx.x;
+    const uint32_t iters = tile_iters[tile];
+    if (r >= (uint32_t)(nlw - 1) + iters) return;
+    const uint32_t pid = tile_pid[tile * 64u + lane];
+    const uint32_t kc = tile_kc[tile * 64u + lane];
+    uint32_t m = 0, n = 0, po = 0, to = 0;
+    if (pid != 0xffffffffu) {
+        const uint32_t la = a_len[pid], lb = b_len[pid];
+        if (la <= lb) { m = la; n = lb; po = a_off[pid]; to = b_off[pid]; }
+        else          { m = lb; n = la; po = b_off[pid]; to = a_off[pid]; }
+    }
+    uint32_t *out = rows + (size_t)tile_off[tile] * 64u + lane;
+    if (r == 0) { out[0] = pid; out[64] = m; out[128] = n; out[192] = kc; }
+    const int kmax = (int)(kc & 0xffffu);
+    const int R0 = diag_first_limb(kmax);
+    const int pblk = (int)((m + 31u) >> 5), tblk = (int)((n + 31u) >> 5);
+    out += META_ROWS * 64;
+    auto limb = [&](int g, int p) -> uint32_t { return (g >= 0 && g < pblk) ? planes[po + (uint32_t)g * NP + p] : 0u; };
+    auto text = [&](int blk, int p) -> uint32_t { return (blk >= 0 && blk < tblk) ? planes[to + (uint32_t)blk * NP + p] : 0u; };
+    if (r < (uint32_t)(nlw - 1)) {
+#pragma unroll
+        for (int p = 0; p < NP; p++) out[(r * NP + p) * 64u] = limb(R0 + (int)r, p);
+        return;
+    }
+    const int it = (int)r - (nlw - 1);
+    out += (size_t)(nlw - 1) * NP * 64u + (size_t)it * 2u * NP * 64u;
+    const int c = 32 * (R0 + it) + kmax;           // first column of this block, may be negative in block 0
+    const int blk = c >> 5;                        // arithmetic shift = floor
+    const uint32_t sh = (uint32_t)c & 31u;
+#pragma unroll
+    for (int p = 0; p < NP; p++) {
+        out[p * 64u] = limb(R0 + it + nlw - 1, p);
+        const uint32_t lo = text(blk, p), hi = text(blk + 1, p);
+        out[(NP + p) * 64u] = sh ? ((lo >> sh) | (hi << (32u - sh))) : lo;
+    }
+}
+
+// ---- one block of 32 columns, skewed inside the lane ---------------------------------------------
+// A wave issues in order, and the straightforward order (limb after limb, column after column) makes
+// every instruction wait for the one before it.  So the limbs of a lane are skewed like the lanes of the
+// full-matrix kernel: in step s limb k works on column s - k.  The carry out of limb k then belongs to
+// the column limb k + 1 handles in the NEXT step, and within a step the NLW limbs are independent:
+// their instructions are interleaved (all first bit-ops, all second ones, the additions, all V'), which
+// puts NLW - 1 independent instructions between an instruction and its consumer.  The skew is filled
+// and drained once per block (NLW - 1 extra steps of 32 + NLW - 1), because the window moves between blocks.
+// Every instruction is its own volatile asm statement: the order written here is the order issued.
+__device__ __forceinline__ uint32_t op_match(uint32_t v, uint32_t p, uint32_t x)      // v & ~(p ^ x)
+{
+    uint32_t d;
+    asm volatile("v_bitop3_b32 %0, %1, %2, %3 bitop3:0x90" : "=v"(d) : "v"(v), "v"(p), "v"(x));
+    return d;
+}
+__device__ __forceinline__ uint32_t op_and(uint32_t a, uint32_t b)
+{
+    uint32_t d;
+    asm volatile("v_and_b32 %0, %1, %2" : "=v"(d) : "v"(a), "v"(b));
+    return d;
+}
+__device__ __forceinline__ uint32_t op_next(uint32_t u, uint32_t sum, uint32_t v)     // sum | (v ^ u)
+{
+    uint32_t d;
+    asm volatile("v_bitop3_b32 %0, %1, %2, %3 bitop3:0xde" : "=v"(d) : "v"(u), "v"(sum), "v"(v));
+    return d;
+}
+__device__ __forceinline__ uint32_t op_add(uint32_t a, uint32_t b, uint64_t &cout)
+{
+    uint32_t d;
+    asm volatile("v_add_co_u32_e64 %0, %1, %2, %3" : "=v"(d), "=s"(cout) : "v"(a), "v"(b));
+    return d;
+}
+__device__ __forceinline__ uint32_t op_addc(uint32_t a, uint32_t b, uint64_t cin, uint64_t &cout)
+{
+    uint32_t d;
+    asm volatile("v_addc_co_u32_e64 %0, %1, %2, %3, %4" : "=v"(d), "=&s"(cout) : "v"(a), "v"(b), "s"(cin));
+    return d;
+}
+
+template <int NLW, int NP>
+struct diag_state {
+    uint32_t x[NLW][NP];      // text bits (sign-extended) of the column each limb works on in this step
+    uint32_t act[NLW];        // ... and whether that column exists (masked blocks only)
+    uint64_t c[NLW + 1];      // c[k]: carry into limb k for the column it handles next (c[0] is never read)
+};
+
+template <int NLW, int NP, bool MASKED, int S>
+__device__ __forceinline__ void diag_step(uint32_t (&V)[NLW], const uint32_t (&P)[NLW][NP], const uint32_t (&w)[NP],
+                                          uint32_t vm, diag_state<NLW, NP> &st)
+{
+    constexpr int klo = S < 32 ? 0 : S - 31;                  // limbs with a column in this step
+    constexpr int khi = S < NLW - 1 ? S : NLW - 1;
+#pragma unroll
+    for (int k = NLW - 1; k >= 1; k--) {
+#pragma unroll
+        for (int q = 0; q < NP; q++) st.x[k][q] = st.x[k - 1][q];
+        st.act[k] = st.act[k - 1];
+    }
+    if constexpr (S < 32) {
+#pragma unroll
+        for (int q = 0; q < NP; q++) st.x[0][q] = (uint32_t)__builtin_amdgcn_sbfe((int)w[q], S, 1);
+        if (MASKED) st.act[0] = (uint32_t)__builtin_amdgcn_sbfe((int)vm, S, 1);
+    }
+    uint32_t t[NLW], sum[NLW];
+#pragma unroll
+    for (int q = 0; q < NP; q++) {
+#pragma unroll
+        for (int k = klo; k <= khi; k++) t[k] = op_match(q ? t[k] : V[k], P[k][q], st.x[k][q]);
+    }
+    if (MASKED) {
+#pragma unroll
+        for (int k = klo; k <= khi; k++) t[k] = op_and(t[k], st.act[k]);
+    }
+#pragma unroll
+    for (int k = khi; k >= klo; k--) {                        // descending: c[k + 1] is consumed before it is rewritten
+        if (k == 0) sum[0] = op_add(V[0], t[0], st.c[1]);
+        else        sum[k] = op_addc(V[k], t[k], st.c[k], st.c[k + 1]);
+    }
+#pragma unroll
+    for (int k = klo; k <= khi; k++) V[k] = op_next(t[k], sum[k], V[k]);
+}
+
+// DNA, three limbs (the default class): the whole unmasked block as ONE asm statement, so that neither
+// compiler pads nor its scheduling get between the instructions.  Temporaries are named registers
+// (clobbered) and the operands are pinned, all chosen so that the three sources of every instruction sit in
+// three different VGPR banks (bank = register number mod 4; tools/diag_micro.hip: 55 T lane-op/s against
+// 42 T when they collide): V v20/v24/v28 and the text words v32/v36 in bank 0, the pattern planes
+// v21/v25/v29 and v33/v37/v41 in bank 1, U per limb v22/v26/v30 in bank 2, the sums v23/v27/v31 and the
+// three rotating pairs of text bits v35,v47 / v39,v51 / v43,v55 in bank 3;
+// the carries into limbs 1 / 2 alternate between s[40:41] / s[42:43] (written by even steps) and
+// s[44:45] / s[46:47] (odd steps), s[48:49] swallows the carry out of the window.
+// Step s: limb 0 on column s (text bits in pair A), limb 1 on column s - 1 (B), limb 2 on column s - 2 (C).
+#define DG_X0 "v35", "v47"
+#define DG_X1 "v39", "v51"
+#define DG_X2 "v43", "v55"
+#define DG_CE "s[40:41]", "s[42:43]"
+#define DG_CO "s[44:45]", "s[46:47]"
+#define DG_BFE(s, A0, A1) "v_bfe_i32 " A0 ", %[w0], " #s ", 1\n\tv_bfe_i32 " A1 ", %[w1], " #s ", 1\n\t"
+#define DG_U0a(A0) "v_bitop3_b32 v22, %[V0], %[P00], " A0 " bitop3:0x90\n\t"
+#define DG_U1a(B0) "v_bitop3_b32 v26, %[V1], %[P10], " B0 " bitop3:0x90\n\t"
+#define DG_U2a(C0) "v_bitop3_b32 v30, %[V2], %[P20], " C0 " bitop3:0x90\n\t"
+#define DG_U0b(A1) "v_bitop3_b32 v22, v22, %[P01], " A1 " bitop3:0x90\n\t"
+#define DG_U1b(B1) "v_bitop3_b32 v26, v26, %[P11], " B1 " bitop3:0x90\n\t"
+#define DG_U2b(C1) "v_bitop3_b32 v30, v30, %[P21], " C1 " bitop3:0x90\n\t"
+#define DG_ADD2(I2) "v_addc_co_u32_e64 v31, s[48:49], %[V2], v30, " I2 "\n\t"
+#define DG_ADD1(I1, O2) "v_addc_co_u32_e64 v27, " O2 ", %[V1], v26, " I1 "\n\t"
+#define DG_ADD0(O1) "v_add_co_u32_e64 v23, " O1 ", %[V0], v22\n\t"
+#define DG_N2 "v_bitop3_b32 %[V2], v30, v31, %[V2] bitop3:0xde\n\t"
+#define DG_N1 "v_bitop3_b32 %[V1], v26, v27, %[V1] bitop3:0xde\n\t"
+#define DG_N0 "v_bitop3_b32 %[V0], v22, v23, %[V0] bitop3:0xde\n\t"
+#define DG_STEP_(s, A0, A1, B0, B1, C0, C1, I1, I2, O1, O2)                                              \
+    DG_BFE(s, A0, A1) DG_U1a(B0) DG_U2a(C0) DG_U0a(A0) DG_U1b(B1) DG_U2b(C1) DG_U0b(A1)                  \
+    DG_ADD2(I2) DG_ADD1(I1, O2) DG_ADD0(O1) DG_N2 DG_N1 DG_N0
+#define DG_STEP_X(s, A0, A1, B0, B1, C0, C1, I1, I2, O1, O2) DG_STEP_(s, A0, A1, B0, B1, C0, C1, I1, I2, O1, O2)
+#define DG_STEP(s, A, B, C, I, O) DG_STEP_X(s, A, B, C, I, O)
+#define DG_FILL0_(s, A0, A1, O1, O2) DG_BFE(s, A0, A1) DG_U0a(A0) DG_U0b(A1) DG_ADD0(O1) DG_N0
+#define DG_FILL0_X(s, A0, A1, O1, O2) DG_FILL0_(s, A0, A1, O1, O2)
+#define DG_FILL0(s, A, O) DG_FILL0_X(s, A, O)
+#define DG_FILL1_(s, A0, A1, B0, B1, I1, I2, O1, O2)                                                     \
+    DG_BFE(s, A0, A1) DG_U1a(B0) DG_U0a(A0) DG_U1b(B1) DG_U0b(A1) DG_ADD1(I1, O2) DG_ADD0(O1) DG_N1 DG_N0
+#define DG_FILL1_X(s, A0, A1, B0, B1, I1, I2, O1, O2) DG_FILL1_(s, A0, A1, B0, B1, I1, I2, O1, O2)
+#define DG_FILL1(s, A, B, I, O) DG_FILL1_X(s, A, B, I, O)
+#define DG_DRAIN1_(B0, B1, C0, C1, I1, I2, O1, O2) DG_U1a(B0) DG_U2a(C0) DG_U1b(B1) DG_U2b(C1) DG_ADD2(I2) DG_ADD1(I1, O2) DG_N2 DG_N1
+#define DG_DRAIN1_X(B0, B1, C0, C1, I1, I2, O1, O2) DG_DRAIN1_(B0, B1, C0, C1, I1, I2, O1, O2)
+#define DG_DRAIN1(B, C, I, O) DG_DRAIN1_X(B, C, I, O)
+#define DG_DRAIN2_(C0, C1, I1, I2) DG_U2a(C0) DG_U2b(C1) DG_ADD2(I2) DG_N2
+#define DG_DRAIN2_X(C0, C1, I1, I2) DG_DRAIN2_(C0, C1, I1, I2)
+#define DG_DRAIN2(C, I) DG_DRAIN2_X(C, I)
+// six steps from an even s with s % 3 == 2: the pairs rotate A = X[s % 3], B = X[(s - 1) % 3], C = X[(s - 2) % 3],
+// even steps read the carries the odd ones wrote and the other way round
+#define DG_SIX(s0, s1, s2, s3, s4, s5)                                                                    \
+    DG_STEP(s0, DG_X2, DG_X1, DG_X0, DG_CO, DG_CE) DG_STEP(s1, DG_X0, DG_X2, DG_X1, DG_CE, DG_CO)        \
+    DG_STEP(s2, DG_X1, DG_X0, DG_X2, DG_CO, DG_CE) DG_STEP(s3, DG_X2, DG_X1, DG_X0, DG_CE, DG_CO)        \
+    DG_STEP(s4, DG_X0, DG_X2, DG_X1, DG_CO, DG_CE) DG_STEP(s5, DG_X1, DG_X0, DG_X2, DG_CE, DG_CO)
+
+// The rows of the next block are loaded by the same statement (issued first, waited for last), because
+// a compiler-visible load in flight makes hipcc drain the memory counter in front of the statement.
+__device__ __forceinline__ void diag_block_dna3(uint32_t (&V)[3], const uint32_t (&P)[3][2], const uint32_t (&w)[2],
+                                                const uint32_t *next_rows, uint32_t (&nxt)[4])
+{
+    register uint32_t V0 asm("v20") = V[0], V1 asm("v24") = V[1], V2 asm("v28") = V[2];
+    register uint32_t P00 asm("v21") = P[0][0], P10 asm("v25") = P[1][0], P20 asm("v29") = P[2][0];
+    register uint32_t P01 asm("v33") = P[0][1], P11 asm("v37") = P[1][1], P21 asm("v41") = P[2][1];
+    register uint32_t w0 asm("v32") = w[0], w1 asm("v36") = w[1];
+    asm volatile(
+        "global_load_dword %[n0], %[np], off\n\tglobal_load_dword %[n1], %[np], off offset:256\n\t"
+        "global_load_dword %[n2], %[np], off offset:512\n\tglobal_load_dword %[n3], %[np], off offset:768\n\t"
+        ".p2align 3\n\ts_nop 0\n\t"             // 64-bit encodings issue a third faster from addresses = 4 (mod 8): tools/diag_micro.hip
+        DG_FILL0(0, DG_X0, DG_CE) DG_FILL1(1, DG_X1, DG_X0, DG_CE, DG_CO)
+        DG_SIX(2, 3, 4, 5, 6, 7) DG_SIX(8, 9, 10, 11, 12, 13) DG_SIX(14, 15, 16, 17, 18, 19)
+        DG_SIX(20, 21, 22, 23, 24, 25) DG_SIX(26, 27, 28, 29, 30, 31)
+        DG_DRAIN1(DG_X1, DG_X0, DG_CO, DG_CE) DG_DRAIN2(DG_X1, DG_CE)
+        "s_waitcnt vmcnt(0)"
+        : [V0] "+v"(V0), [V1] "+v"(V1), [V2] "+v"(V2),
+          [n0] "=&v"(nxt[0]), [n1] "=&v"(nxt[1]), [n2] "=&v"(nxt[2]), [n3] "=&v"(nxt[3])
+        : [np] "v"(next_rows), [P00] "v"(P00), [P01] "v"(P01), [P10] "v"(P10), [P11] "v"(P11), [P20] "v"(P20), [P21] "v"(P21),
+          [w0] "v"(w0), [w1] "v"(w1)
+        : "v22", "v26", "v30", "v23", "v27", "v31", "v35", "v47", "v39", "v51", "v43", "v55",
+          "s40", "s41", "s42", "s43", "s44", "s45", "s46", "s47", "s48", "s49");
+    V[0] = V0; V[1] = V1; V[2] = V2;
+}
+
+// The same for the other classes: loads the compiler does not see, and a wait statement that every
+// destination passes through before its first use (the loads are unconditional: the buffer is padded).
+template <int J>
+__device__ __forceinline__ void row_load_async(const uint32_t *p, uint32_t &dst)
+{
+    asm volatile("global_load_dword %0, %1, off offset:%2" : "=v"(dst) : "v"(p), "n"(J * 256));
+}
+template <int N, int... J>
+__device__ __forceinline__ void rows_load_async(const uint32_t *p, uint32_t (&dst)[N], std::integer_sequence<int, J...>)
+{
+    (row_load_async<J>(p, dst[J]), ...);
+}
+template <int N>
+__device__ __forceinline__ void rows_wait(uint32_t (&dst)[N])
+{
+    asm volatile("s_waitcnt vmcnt(0)" : "+v"(dst[0]));
+#pragma unroll
+    for (int j = 1; j < N; j++) asm volatile("" : "+v"(dst[j]));
+}
+
+template <int NLW, int NP, bool MASKED, int... S>
+__device__ __forceinline__ void diag_block(uint32_t (&V)[NLW], const uint32_t (&P)[NLW][NP], const uint32_t (&w)[NP],
+                                           uint32_t vm, std::integer_sequence<int, S...>)
+{
+    diag_state<NLW, NP> st;
+    (diag_step<NLW, NP, MASKED, S>(V, P, w, vm, st), ...);
+}
+
+// ---- the window kernel -------------------------------------------------------------------------
+template <int NLW, int NP, bool FUSED = true>
+__global__ void __launch_bounds__(64)
+k_llcs_diag(const uint32_t *__restrict__ rows, const uint32_t *__restrict__ tile_off,
+            const uint32_t *__restrict__ tile_iters, int32_t *__restrict__ dist,
+            uint32_t *__restrict__ retry_list, const uint32_t *__restrict__ retry_first,
+            const uint32_t *__restrict__ retry_cap, uint32_t *__restrict__ retry_count)
+{
+    constexpr int T = 32 * NLW - 32;
+    const unsigned lane = threadIdx.x;
+    const uint32_t tile = blockIdx.x;
+    const uint32_t *p = rows + (size_t)__builtin_amdgcn_readfirstlane(tile_off[tile]) * 64u + lane;
+    const int iters = (int)__builtin_amdgcn_readfirstlane(tile_iters[tile]);
+    const uint32_t pid = p[0], m = p[64], n = p[128], kc = p[192];
+    const int kmax = (int)(kc & 0xffffu);
+    const int R0 = diag_first_limb(kmax);
+    const int c0 = 32 * R0 + kmax;                 // column of step 0 of block 0, in (-32, 0]
+    p += META_ROWS * 64;
+
+    uint32_t P[NLW][NP], V[NLW];
+#pragma unroll
+    for (int k = 0; k < NLW - 1; k++) {
+#pragma unroll
+        for (int q = 0; q < NP; q++) P[k][q] = p[(k * NP + q) * 64];
+        V[k] = (R0 + k >= 0) ? ~0u : 0u;           // rows above the matrix: V = 0 neither matches nor carries
+    }
+    p += (NLW - 1) * NP * 64;
+    uint32_t nxt[2 * NP];
+    rows_load_async(p, nxt, std::make_integer_sequence<int, 2 * NP>());
+    rows_wait(nxt);
+
+    auto rowmask = [&](int g) -> uint32_t {        // rows of limb g that exist
+        const int vb = (int)m - 32 * g;
+        return (g < 0 || vb <= 0) ? 0u : (vb >= 32 ? ~0u : ((1u << vb) - 1u));
+    };
+    uint32_t banked = 0;
+
+    for (int it = 0; it < iters; it++) {
+        uint32_t w[NP];
+#pragma unroll
+        for (int q = 0; q < NP; q++) { P[NLW - 1][q] = nxt[q]; w[q] = nxt[NP + q]; }
+        V[NLW - 1] = ~0u;
+        p += 2 * NP * 64;                          // rows of the next block (the buffer ends with one block of padding)
+        const int lo = -(c0 + 32 * it);            // first and one-past-last valid step of the block
+        const int hi = (int)n - (c0 + 32 * it);
+        const uint32_t mlo = lo <= 0 ? ~0u : (lo >= 32 ? 0u : (~0u << lo));
+        const uint32_t mhi = hi >= 32 ? ~0u : (hi <= 0 ? 0u : ((1u << hi) - 1u));
+        const uint32_t vm = mlo & mhi;
+        const bool fast = __builtin_amdgcn_ballot_w64(vm != ~0u) == 0;
+        if constexpr (NLW == 3 && NP == 2 && FUSED) {
+            if (fast) {
+                diag_block_dna3(V, P, w, p, nxt);
+            } else {                               // first / last blocks: steps outside [0, n) must not change V
+                rows_load_async(p, nxt, std::make_integer_sequence<int, 2 * NP>());
+                diag_block<NLW, NP, true>(V, P, w, vm, std::make_integer_sequence<int, 32 + NLW - 1>());
+                rows_wait(nxt);
+            }
+        } else {
+            rows_load_async(p, nxt, std::make_integer_sequence<int, 2 * NP>());
+            if (fast) diag_block<NLW, NP, false>(V, P, w, vm, std::make_integer_sequence<int, 32 + NLW - 1>());
+            else      diag_block<NLW, NP, true>(V, P, w, vm, std::make_integer_sequence<int, 32 + NLW - 1>());
+            rows_wait(nxt);
+        }
+        // the window moves down one limb
+        banked += __popc(~V[0] & rowmask(R0 + it));
+#pragma unroll
+        for (int k = 0; k < NLW - 1; k++) {
+            V[k] = V[k + 1];
+#pragma unroll
+            for (int q = 0; q < NP; q++) P[k][q] = P[k + 1][q];
+        }
+    }
+    uint32_t zeros = banked;
+#pragma unroll
+    for (int k = 0; k < NLW - 1; k++) zeros += __popc(~V[k] & rowmask(R0 + iters + k));
+
+    if (pid != 0xffffffffu) {
+        const int32_t d = (int32_t)(m + n - 2u * zeros);
+        if (d <= T) {
+            dist[pid] = d;
+        } else {
+            const uint32_t cls = kc >> 16;
+            const uint32_t idx = atomicAdd(&retry_count[cls], 1u);
+            if (idx < retry_cap[cls]) retry_list[retry_first[cls] + idx] = pid;
+        }
+    }
+}
+
+typedef void (*diag_kernel_t)(const uint32_t *, const uint32_t *, const uint32_t *, int32_t *, uint32_t *,
+                              const uint32_t *, const uint32_t *, uint32_t *);
+template <int NP>
+diag_kernel_t pick_diag(int nlw)
+{
+    switch (nlw) {
+    case 2: return k_llcs_diag<2, NP>;
+    case 3: if (getenv("MALCS_DIAG_GENERIC")) return k_llcs_diag<3, NP, false>; else return k_llcs_diag<3, NP>;   // dev switch: A/B the fused block
+    case 4: return k_llcs_diag<4, NP>;
+    case 5: return k_llcs_diag<5, NP>;
+    case 8: return k_llcs_diag<8, NP>;
+    default: return nullptr;
+    }
+}
+
+}  // namespace
+
+int malcs_diag_threshold(int nlw) { return 32 * nlw - 32; }
+
+void malcs_diag_release(malcs_batch *b)
+{
+    diag_plan &d = b->diag;
+    hipFree(d.d_rows); hipFree(d.d_tile_off); hipFree(d.d_tile_iters);
+    hipFree(d.d_retry_list); hipFree(d.d_retry_first); hipFree(d.d_retry_cap); hipFree(d.d_retry_count);
+    d = diag_plan();
+}
+
+int malcs_diag_plan(malcs_batch *b, int nlw, const std::vector<uint32_t> &pairs, const std::vector<uint8_t> &retry_class,
+                    const std::vector<diag_retry> &classes)
+{
+    diag_plan &d = b->diag;
+    d = diag_plan();
+    if (pairs.empty()) return MALCS_OK;
+    if (b->n_planes > 4 || !(nlw == 2 || nlw == 3 || nlw == 4 || nlw == 5 || nlw == 8)) {
+        malcs_set_error("no window kernel for %d limbs and %d bit planes", nlw, b->n_planes);
+        return MALCS_ERR_INTERNAL;
+    }
+    const int T = malcs_diag_threshold(nlw);
+    struct item { uint32_t pid, kc, iters; };
+    std::vector<item> items(pairs.size());
+    uint64_t cells = 0;
+    for (size_t i = 0; i < pairs.size(); i++) {
+        const uint32_t pid = pairs[i];
+        const uint32_t m = std::min(b->a_len[pid], b->b_len[pid]), n = std::max(b->a_len[pid], b->b_len[pid]);
+        const int delta = (int)(n - m);
+        if (delta > T || n == 0) { malcs_set_error("pair %u does not fit the window class", pid); return MALCS_ERR_INTERNAL; }
+        const int kmax = delta + (T - delta) / 2;
+        const int c0 = 32 * diag_first_limb(kmax) + kmax;
+        items[i] = {pid, (uint32_t)kmax | ((uint32_t)retry_class[i] << 16), (uint32_t)(((int)n - 1 - c0) / 32 + 1)};
+        cells += (uint64_t)(32 * nlw) * n;
+    }
+    std::stable_sort(items.begin(), items.end(), [](const item &x, const item &y) { return x.iters < y.iters; });
+    const uint32_t n_tiles = (uint32_t)((items.size() + 63) / 64);
+    std::vector<uint32_t> tile_pid((size_t)n_tiles * 64, 0xffffffffu), tile_kc((size_t)n_tiles * 64, 0u);
+    std::vector<uint32_t> tile_off(n_tiles + 1), tile_iters(n_tiles);
+    uint64_t row = 0;
+    uint32_t max_rows = 0;
+    for (uint32_t t = 0; t < n_tiles; t++) {
+        uint32_t it = 1;
+        for (size_t i = (size_t)t * 64; i < std::min(items.size(), (size_t)(t + 1) * 64); i++) {
+            tile_pid[i] = items[i].pid; tile_kc[i] = items[i].kc; it = std::max(it, items[i].iters);
+        }
+        tile_off[t] = (uint32_t)row; tile_iters[t] = it;
+        const uint32_t r = (uint32_t)(nlw - 1) + it;
+        max_rows = std::max(max_rows, r);
+        row += (uint64_t)META_ROWS + (uint64_t)(nlw - 1) * b->n_planes + (uint64_t)it * 2u * b->n_planes;
+        if (row >= 0xffffffffull) { malcs_set_error("window class too large; split the batch"); return MALCS_ERR_TOO_LONG; }
+    }
+    tile_off[n_tiles] = (uint32_t)row;
+
+    // retry bookkeeping: one list segment per full-matrix class, sized for the worst case
+    d.retry = classes;
+    std::vector<uint32_t> cap(classes.size(), 0), first(classes.size(), 0);
+    for (size_t i = 0; i < pairs.size(); i++) cap[retry_class[i]]++;
+    uint32_t acc = 0;
+    for (size_t c = 0; c < classes.size(); c++) { first[c] = acc; acc += cap[c]; d.retry[c].first = first[c]; d.retry[c].cap = cap[c]; }
+
+    hipStream_t st = b->ctx->stream;
+    uint32_t *d_tile_pid = nullptr, *d_tile_kc = nullptr;
+    const size_t ncls = std::max<size_t>(classes.size(), 1);
+    MALCS_HIP(hipMalloc(&d.d_rows, ((size_t)row + 2u * b->n_planes) * 64u * sizeof(uint32_t)));   // + one block of padding: the kernel prefetches unconditionally
+    MALCS_HIP(hipMalloc(&d.d_tile_off, (n_tiles + 1) * sizeof(uint32_t)));
+    MALCS_HIP(hipMalloc(&d.d_tile_iters, n_tiles * sizeof(uint32_t)));
+    MALCS_HIP(hipMalloc(&d.d_retry_list, (size_t)std::max<uint32_t>(acc, 1) * sizeof(uint32_t)));
+    MALCS_HIP(hipMalloc(&d.d_retry_first, ncls * sizeof(uint32_t)));
+    MALCS_HIP(hipMalloc(&d.d_retry_cap, ncls * sizeof(uint32_t)));
+    MALCS_HIP(hipMalloc(&d.d_retry_count, ncls * sizeof(uint32_t)));
+    MALCS_HIP(hipMalloc(&d_tile_pid, tile_pid.size() * sizeof(uint32_t)));
+    MALCS_HIP(hipMalloc(&d_tile_kc, tile_kc.size() * sizeof(uint32_t)));
+    MALCS_HIP(hipMemcpyAsync(d.d_tile_off, tile_off.data(), (n_tiles + 1) * sizeof(uint32_t), hipMemcpyHostToDevice, st));
+    MALCS_HIP(hipMemcpyAsync(d.d_tile_iters, tile_iters.data(), n_tiles * sizeof(uint32_t), hipMemcpyHostToDevice, st));
+    MALCS_HIP(hipMemcpyAsync(d_tile_pid, tile_pid.data(), tile_pid.size() * sizeof(uint32_t), hipMemcpyHostToDevice, st));
+    MALCS_HIP(hipMemcpyAsync(d_tile_kc, tile_kc.data(), tile_kc.size() * sizeof(uint32_t), hipMemcpyHostToDevice, st));
+    if (!classes.empty()) {
+        MALCS_HIP(hipMemcpyAsync(d.d_retry_first, first.data(), classes.size() * sizeof(uint32_t), hipMemcpyHostToDevice, st));
+        MALCS_HIP(hipMemcpyAsync(d.d_retry_cap, cap.data(), classes.size() * sizeof(uint32_t), hipMemcpyHostToDevice, st));
+    }
+    MALCS_HIP(hipMemsetAsync(d.d_retry_count, 0, ncls * sizeof(uint32_t), st));
+    const dim3 grid(max_rows, n_tiles), block(64);
+    switch (b->n_planes) {
+    case 2: hipLaunchKernelGGL(k_diag_layout<2>, grid, block, 0, st, b->d_planes, b->d_a_off, b->d_a_len, b->d_b_off, b->d_b_len, d_tile_pid, d_tile_kc, d.d_tile_off, d.d_tile_iters, nlw, d.d_rows); break;
+    case 3: hipLaunchKernelGGL(k_diag_layout<3>, grid, block, 0, st, b->d_planes, b->d_a_off, b->d_a_len, b->d_b_off, b->d_b_len, d_tile_pid, d_tile_kc, d.d_tile_off, d.d_tile_iters, nlw, d.d_rows); break;
+    case 4: hipLaunchKernelGGL(k_diag_layout<4>, grid, block, 0, st, b->d_planes, b->d_a_off, b->d_a_len, b->d_b_off, b->d_b_len, d_tile_pid, d_tile_kc, d.d_tile_off, d.d_tile_iters, nlw, d.d_rows); break;
+    }
+    MALCS_HIP(hipGetLastError());
+    MALCS_HIP(hipStreamSynchronize(st));           // the host vectors above are locals
+    hipFree(d_tile_pid); hipFree(d_tile_kc);
+    d.nlw = nlw; d.T = T; d.n_tiles = n_tiles; d.n_pairs = (uint32_t)pairs.size(); d.window_cells = cells;
+    return MALCS_OK;
+}
+
+int malcs_diag_launch(malcs_batch *b, bool reset_counters)
+{
+    diag_plan &d = b->diag;
+    if (!d.nlw) return MALCS_OK;
+    hipStream_t st = b->ctx->stream;
+    if (reset_counters && !d.retry.empty()) MALCS_HIP(hipMemsetAsync(d.d_retry_count, 0, d.retry.size() * sizeof(uint32_t), st));
+    diag_kernel_t fn = nullptr;
+    switch (b->n_planes) {
+    case 2: fn = pick_diag<2>(d.nlw); break;
+    case 3: fn = pick_diag<3>(d.nlw); break;
+    case 4: fn = pick_diag<4>(d.nlw); break;
+    }
+    if (!fn) { malcs_set_error("no window kernel for %d limbs and %d bit planes", d.nlw, b->n_planes); return MALCS_ERR_INTERNAL; }
+    hipLaunchKernelGGL(fn, dim3(d.n_tiles), dim3(64), 0, st, d.d_rows, d.d_tile_off, d.d_tile_iters, b->d_dist,
+                       d.d_retry_list, d.d_retry_first, d.d_retry_cap, d.d_retry_count);
+    MALCS_HIP(hipGetLastError());
+    return MALCS_OK;
+}

@@ -40,18 +40,17 @@ using namespace malcs_dev;
 #define MALCS_MINW 8
 #endif
 template <int W, int NP, bool XL>
-__global__ void __launch_bounds__(256, MALCS_MINW)
-k_llcs_bitpar(const uint32_t *__restrict__ planes,
-              const uint32_t *__restrict__ a_off, const uint32_t *__restrict__ a_len,
-              const uint32_t *__restrict__ b_off, const uint32_t *__restrict__ b_len,
-              const uint32_t *__restrict__ order, uint32_t first, uint32_t count, int logL,
-              int32_t *__restrict__ dist)
+__device__ __forceinline__ void
+llcs_bitpar_wave(const uint32_t *__restrict__ planes,
+                 const uint32_t *__restrict__ a_off, const uint32_t *__restrict__ a_len,
+                 const uint32_t *__restrict__ b_off, const uint32_t *__restrict__ b_len,
+                 const uint32_t *__restrict__ order, uint32_t first, uint32_t count, int logL,
+                 int32_t *__restrict__ dist, unsigned wave)
 {
     constexpr int NL = 2 * W;
     constexpr int UC = NL <= 8 ? MALCS_UC : (NL <= 16 ? 8 : 4);   // columns unrolled per inner trip
     const unsigned L = 1u << logL;
     const unsigned lane = threadIdx.x & 63u;
-    const unsigned wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
     const unsigned q = XL ? (lane & (L - 1u)) : 0u;
     const unsigned slot = wave * (64u >> logL) + (lane >> logL);
     const bool valid = slot < count;
@@ -138,6 +137,37 @@ k_llcs_bitpar(const uint32_t *__restrict__ planes,
     }
     if (XL) for (unsigned s = 1; s < L; s <<= 1) zeros += __shfl_xor(zeros, s);
     if (valid && q == 0) dist[pid] = (int32_t)(m + n - 2u * zeros);
+}
+
+template <int W, int NP, bool XL>
+__global__ void __launch_bounds__(256, MALCS_MINW)
+k_llcs_bitpar(const uint32_t *__restrict__ planes,
+              const uint32_t *__restrict__ a_off, const uint32_t *__restrict__ a_len,
+              const uint32_t *__restrict__ b_off, const uint32_t *__restrict__ b_len,
+              const uint32_t *__restrict__ order, uint32_t first, uint32_t count, int logL,
+              int32_t *__restrict__ dist)
+{
+    llcs_bitpar_wave<W, NP, XL>(planes, a_off, a_len, b_off, b_len, order, first, count, logL, dist,
+                                (blockIdx.x * blockDim.x + threadIdx.x) >> 6);
+}
+
+// The same waves over a work list whose length is only known on the device (the pairs the window
+// kernel of malcs_diag.hip could not settle): a fixed grid, every wave takes slots until the list is
+// exhausted.  The count is read once, so every wave leaves the loop.
+template <int W, int NP, bool XL>
+__global__ void __launch_bounds__(256, MALCS_MINW)
+k_llcs_bitpar_list(const uint32_t *__restrict__ planes,
+                   const uint32_t *__restrict__ a_off, const uint32_t *__restrict__ a_len,
+                   const uint32_t *__restrict__ b_off, const uint32_t *__restrict__ b_len,
+                   const uint32_t *__restrict__ list, uint32_t first, const uint32_t *__restrict__ count_ptr,
+                   uint32_t cap, int logL, int32_t *__restrict__ dist)
+{
+    uint32_t count = __builtin_amdgcn_readfirstlane(*count_ptr);
+    if (count > cap) count = cap;
+    const unsigned ppw = 64u >> logL;
+    const unsigned nwaves = (gridDim.x * blockDim.x) >> 6;
+    for (unsigned wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6; wave * ppw < count; wave += nwaves)
+        llcs_bitpar_wave<W, NP, XL>(planes, a_off, a_len, b_off, b_len, list, first, count, logL, dist, wave);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -296,6 +326,21 @@ band_kernel_t pick_band(int W)
 
 typedef void (*dist_kernel_t)(const uint32_t *, const uint32_t *, const uint32_t *, const uint32_t *,
                               const uint32_t *, const uint32_t *, uint32_t, uint32_t, int, int32_t *);
+typedef void (*list_kernel_t)(const uint32_t *, const uint32_t *, const uint32_t *, const uint32_t *,
+                              const uint32_t *, const uint32_t *, uint32_t, const uint32_t *, uint32_t, int, int32_t *);
+
+template <int NP>
+list_kernel_t pick_list_kernel(int W, bool xl)
+{
+    switch (W) {
+    case 1: return xl ? k_llcs_bitpar_list<1, NP, true> : k_llcs_bitpar_list<1, NP, false>;
+    case 2: return xl ? k_llcs_bitpar_list<2, NP, true> : k_llcs_bitpar_list<2, NP, false>;
+    case 4: return xl ? k_llcs_bitpar_list<4, NP, true> : k_llcs_bitpar_list<4, NP, false>;
+    case 8: if constexpr (NP <= 4) return k_llcs_bitpar_list<8, NP, true>; else return nullptr;
+    case 16: if constexpr (NP <= 3) return k_llcs_bitpar_list<16, NP, true>; else return nullptr;
+    default: return nullptr;
+    }
+}
 
 template <int NP>
 dist_kernel_t pick_kernel(int W, bool xl)
@@ -350,11 +395,43 @@ int malcs_dist_plan(malcs_batch *b)
         }
         cls[i] = (uint8_t)class_of(W, logL);
     }
+    // Window class (malcs_diag.hip): pairs long enough that a few limbs around the diagonal are much
+    // less work than the whole matrix, and whose length difference alone does not already exceed what
+    // the window can prove.  Whatever it cannot settle returns to the class chosen above.
+    int nlw = 3;
+    if (const char *e = getenv("MALCS_DIAG_NLW")) nlw = atoi(e);
+    std::vector<uint32_t> diag_pairs;
+    std::vector<uint8_t> diag_cls;
+    b->full_cells = 0;
+    for (uint64_t i = 0; i < n; i++) b->full_cells += (uint64_t)b->a_len[i] * b->b_len[i];
+    if (nlw > 0 && b->n_planes <= 4) {
+        const uint32_t T = (uint32_t)malcs_diag_threshold(nlw);
+        for (uint64_t i = 0; i < n; i++) {
+            if (cls[i] == 255) continue;
+            const uint32_t m = std::min(b->a_len[i], b->b_len[i]), mx = std::max(b->a_len[i], b->b_len[i]);
+            if ((m + 31u) / 32u >= 2u * (uint32_t)nlw + 2u && mx - m <= T) diag_pairs.push_back((uint32_t)i);
+        }
+        if (diag_pairs.size() < 64) diag_pairs.clear();
+    }
+    malcs_diag_release(b);
+    if (!diag_pairs.empty()) {
+        std::vector<int> retry_id(table.size(), -1);
+        std::vector<diag_retry> classes;
+        for (uint32_t pid : diag_pairs) {
+            int &id = retry_id[cls[pid]];
+            if (id < 0) { id = (int)classes.size(); diag_retry r; r.W = table[cls[pid]].W; r.L = 1 << table[cls[pid]].logL; classes.push_back(r); }
+            diag_cls.push_back((uint8_t)id);
+            cls[pid] = 254;                        // not in the direct launches
+        }
+        int rc = malcs_diag_plan(b, nlw, diag_pairs, diag_cls, classes);
+        if (rc) return rc;
+    }
+
     std::vector<uint32_t> cnt(table.size() + 1, 0);
-    for (uint64_t i = 0; i < n; i++) if (cls[i] != 255) cnt[cls[i] + 1]++;
+    for (uint64_t i = 0; i < n; i++) if (cls[i] < 254) cnt[cls[i] + 1]++;
     for (size_t c = 0; c < table.size(); c++) cnt[c + 1] += cnt[c];
     std::vector<uint32_t> order(n), pos(cnt.begin(), cnt.end() - 1);
-    for (uint64_t i = 0; i < n; i++) if (cls[i] != 255) order[pos[cls[i]]++] = (uint32_t)i;
+    for (uint64_t i = 0; i < n; i++) if (cls[i] < 254) order[pos[cls[i]]++] = (uint32_t)i;
     b->dist_buckets.clear();
     for (size_t c = 0; c < table.size(); c++) {
         dist_bucket k;
@@ -371,6 +448,29 @@ int malcs_dist_plan(malcs_batch *b)
 
 int malcs_dist_launch(malcs_batch *b)
 {
+    // window class first, then the full-matrix kernel over whatever it left undecided
+    if (b->diag.nlw) {
+        int rc = malcs_diag_launch(b, true);
+        if (rc) return rc;
+        for (size_t c = 0; c < b->diag.retry.size(); c++) {
+            const diag_retry &r = b->diag.retry[c];
+            if (!r.cap) continue;
+            int logL = 0;
+            while ((1 << logL) < r.L) logL++;
+            list_kernel_t fn = nullptr;
+            switch (b->n_planes) {
+            case 2: fn = pick_list_kernel<2>(r.W, r.L > 1); break;
+            case 3: fn = pick_list_kernel<3>(r.W, r.L > 1); break;
+            case 4: fn = pick_list_kernel<4>(r.W, r.L > 1); break;
+            }
+            if (!fn) { malcs_set_error("no distance kernel for W=%d planes=%d", r.W, b->n_planes); return MALCS_ERR_INTERNAL; }
+            const uint32_t ppw = 64u / (uint32_t)r.L;
+            const uint32_t waves = std::min<uint32_t>((r.cap + ppw - 1u) / ppw, 1024u);
+            hipLaunchKernelGGL(fn, dim3((waves + 3u) / 4u), dim3(256), 0, b->ctx->stream, b->d_planes, b->d_a_off, b->d_a_len,
+                               b->d_b_off, b->d_b_len, b->diag.d_retry_list, r.first, b->diag.d_retry_count + c, r.cap, logL, b->d_dist);
+            MALCS_HIP(hipGetLastError());
+        }
+    }
     for (const dist_bucket &k : b->dist_buckets) {
         int logL = 0;
         while ((1 << logL) < k.L) logL++;

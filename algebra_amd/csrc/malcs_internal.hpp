@@ -33,6 +33,24 @@ struct dist_bucket {
     uint32_t count = 0;
 };
 
+// Window kernel (malcs_diag.hip): similar pairs, one lane per pair, a few limbs around the main diagonal.
+struct diag_retry {        // pairs the window could not settle go back to their full-matrix class
+    int W = 0, L = 0;
+    uint32_t first = 0;    // range [first, first + cap) of d_retry_list
+    uint32_t cap = 0;
+};
+struct diag_plan {
+    int nlw = 0;                         // limbs in the window (0: no window class in this batch)
+    int T = 0;                           // results <= T are exact
+    uint32_t n_tiles = 0, n_pairs = 0;
+    uint64_t window_cells = 0;           // sum over the class of 32 * nlw * (text length)
+    uint32_t *d_rows = nullptr;          // tiles of 64 pairs, lane-interleaved rows of 64 dwords
+    uint32_t *d_tile_off = nullptr;      // first row of each tile
+    uint32_t *d_tile_iters = nullptr;    // column blocks of each tile
+    uint32_t *d_retry_list = nullptr, *d_retry_first = nullptr, *d_retry_cap = nullptr, *d_retry_count = nullptr;
+    std::vector<diag_retry> retry;
+};
+
 struct malcs_batch {
     malcs_ctx *ctx = nullptr;
     uint64_t n_pairs = 0;
@@ -46,6 +64,8 @@ struct malcs_batch {
     std::vector<uint32_t> a_off, a_len, b_off, b_len;   // dword offsets into d_planes / lengths in symbols
     std::vector<dist_bucket> dist_buckets;
     std::vector<uint32_t> band_pairs;    // pairs too long for a resident pattern: sliding-window kernel
+    diag_plan diag;
+    uint64_t full_cells = 0;             // sum of m * n over the batch
     uint64_t arena_dwords = 0;
     uint32_t max_len = 0;
 };
@@ -54,6 +74,14 @@ struct malcs_batch {
 int malcs_pack_launch(malcs_ctx *ctx, const uint8_t *d_syms, const uint64_t *d_seq_byte_off,
                       const uint32_t *d_seq_len, const uint32_t *d_seq_blk_off, uint32_t n_seqs,
                       uint32_t total_blocks, int n_planes, uint32_t *d_planes);
+
+// malcs_diag.hip
+// pairs[i] goes to the window class; retry_class[i] indexes `classes` (its full-matrix launch class)
+int malcs_diag_plan(malcs_batch *b, int nlw, const std::vector<uint32_t> &pairs, const std::vector<uint8_t> &retry_class,
+                    const std::vector<diag_retry> &classes);
+int malcs_diag_launch(malcs_batch *b, bool reset_counters);
+void malcs_diag_release(malcs_batch *b);
+int malcs_diag_threshold(int nlw);
 
 // malcs_dist.hip
 int malcs_dist_plan(malcs_batch *b);

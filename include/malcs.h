@@ -76,6 +76,11 @@ uint64_t malcs_batch_size(const malcs_batch *batch);
  * Stands in for edit_distance(a, b) (algebra/lcs/edit_distance.py:21-53):
  * dist[i] = a_len[i] + b_len[i] - 2 * LLCS(a_i, b_i).
  *
+ * Three kernels share the work, chosen per pair when the batch is created: similar pairs of some
+ * length first run in a window of a few limbs around the main diagonal (exact when the result is at
+ * most the window's threshold, otherwise redone), everything else over the full matrix, sequences
+ * beyond a resident pattern in a sliding band.  The results are the same whichever kernel ran.
+ *
  * _launch enqueues the kernels on the context's stream and returns; the distances stay in HBM.
  * _fetch waits for them and copies them to `dist` (n_pairs int32).  _time runs `iters`
  * back-to-back launches between two HIP events on that stream and reports the elapsed
@@ -83,6 +88,16 @@ uint64_t malcs_batch_size(const malcs_batch *batch);
 int malcs_edit_distance_launch(malcs_batch *batch);
 int malcs_edit_distance_fetch(malcs_batch *batch, int32_t *dist);
 int malcs_edit_distance_time(malcs_batch *batch, int iters, float *ms_total);
+
+/* What the planner decided for this batch (for reports; bench.py prices its roofline with it):
+ * info[0] pairs in the window class, [1] limbs (32 rows each) in the window, [2] its threshold T
+ * (results <= T are final, others are redone over the full matrix), [3] cells the window class computes
+ * = sum 32 * limbs * max(m, n), [4] full-matrix cells of the whole batch = sum m * n,
+ * [5] number of full-matrix launch classes. */
+int malcs_batch_plan_info(const malcs_batch *batch, uint64_t *info6);
+/* As _time, but only the batch's dominant kernel (the window kernel when the batch has a window class,
+ * else the full-matrix launches), so that its duration can be set against rocprofv3's. */
+int malcs_edit_distance_time_kernel(malcs_batch *batch, int iters, float *ms_total);
 
 /* One-shot convenience: create + launch + fetch + destroy. */
 int malcs_edit_distance_batch(malcs_ctx *ctx, const uint8_t *syms, uint64_t n_syms,

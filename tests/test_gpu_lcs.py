@@ -134,6 +134,65 @@ def test_edit_distance_c2_full_size(native):
     assert 15 < d.mean() < 25
 
 
+def _window_class_batch(rs, n_pairs, nsym):
+    """Pairs long enough for the window class, divergence from identical to unrelated, length gaps up to 300."""
+    seqs = []
+    for i in range(n_pairs):
+        length = int(rs.randint(250, 2600))
+        a = rs.randint(0, nsym, length).astype(np.uint8)
+        kind = i % 8
+        if kind == 0:
+            b = a.copy()
+        elif kind == 7:
+            b = rs.randint(0, nsym, max(1, length + rs.randint(-300, 301))).astype(np.uint8)
+        else:
+            p = [0.002, 0.005, 0.01, 0.02, 0.04, 0.1][kind - 1]
+            keep = rs.random_sample(length) >= p
+            ins = rs.random_sample(length) < p
+            out = []
+            for j in range(length):
+                if ins[j]:
+                    out.append(rs.randint(0, nsym))
+                if keep[j]:
+                    out.append(a[j])
+            b = np.array(out, dtype=np.uint8)
+            if kind == 3:                            # one long gap on top: length difference beyond small windows
+                cut = rs.randint(0, len(b) // 2)
+                b = np.concatenate([b[:cut], b[cut + rs.randint(20, 140):]])
+        if i % 3 == 0:
+            a, b = b, a
+        seqs.append((a, b))
+    syms = np.concatenate([x for ab in seqs for x in ab] + [np.zeros(1, np.uint8)])
+    a_off, a_len, b_off, b_len = [], [], [], []
+    pos = 0
+    for a, b in seqs:
+        a_off.append(pos); a_len.append(len(a)); pos += len(a)
+        b_off.append(pos); b_len.append(len(b)); pos += len(b)
+    return (syms, np.array(a_off, np.uint64), np.array(a_len, np.uint32), np.array(b_off, np.uint64),
+            np.array(b_len, np.uint32))
+
+
+@pytest.mark.parametrize("nlw,nsym", [(3, 4), (2, 4), (4, 3), (5, 4), (8, 2), (3, 7), (4, 13), (0, 4)])
+def test_edit_distance_window_class(native, nlw, nsym, monkeypatch):
+    """The window class (malcs_diag.hip) for every window size, with pairs it settles, pairs it hands
+    back to the full-matrix kernel and pairs that never enter it; nlw = 0 switches the class off."""
+    from oracle import oracle as O
+    monkeypatch.setenv("MALCS_DIAG_NLW", str(nlw))
+    data = _window_class_batch(np.random.RandomState(100 + nlw + nsym), 1500, nsym)
+    batch = native.Batch(native.default_context(), *data, n_symbols=nsym)
+    info = batch.plan_info()
+    assert (info["window_pairs"] > 0) == (nlw > 0)
+    assert info["window_limbs"] == (nlw if nlw else 0)
+    got = batch.distances()
+    again = batch.distances()                      # second launch: the retry counters start over
+    batch.close()
+    ref = O.edit_distance_batch(*data)
+    assert np.array_equal(got, ref)
+    assert np.array_equal(again, ref)
+    if nlw:
+        assert (ref > 32 * nlw - 32).sum() > 50 and (ref <= 32 * nlw - 32).sum() > 50
+
+
 def test_empty_batch_and_bad_arguments(native):
     import algebra_amd
     assert algebra_amd.edit_distance_batch([]).tolist() == []
