@@ -286,9 +286,12 @@ __global__ void __launch_bounds__(64)
 k_llcs_diag(const uint32_t *__restrict__ rows, const uint32_t *__restrict__ tile_off,
             const uint32_t *__restrict__ tile_iters, int32_t *__restrict__ dist,
             uint32_t *__restrict__ retry_list, const uint32_t *__restrict__ retry_first,
-            const uint32_t *__restrict__ retry_cap, uint32_t *__restrict__ retry_count)
+            const uint32_t *__restrict__ retry_cap, uint32_t *__restrict__ retry_count,
+            uint32_t *__restrict__ retry_count_next, uint32_t n_classes)
 {
     constexpr int T = 32 * NLW - 32;
+    // the counters of the NEXT launch start at zero: nothing in flight reads or writes that set now
+    if (blockIdx.x == 0 && threadIdx.x < n_classes) retry_count_next[threadIdx.x] = 0u;
     const unsigned lane = threadIdx.x;
     const uint32_t tile = blockIdx.x;
     const uint32_t *p = rows + (size_t)__builtin_amdgcn_readfirstlane(tile_off[tile]) * 64u + lane;
@@ -369,7 +372,7 @@ k_llcs_diag(const uint32_t *__restrict__ rows, const uint32_t *__restrict__ tile
 }
 
 typedef void (*diag_kernel_t)(const uint32_t *, const uint32_t *, const uint32_t *, int32_t *, uint32_t *,
-                              const uint32_t *, const uint32_t *, uint32_t *);
+                              const uint32_t *, const uint32_t *, uint32_t *, uint32_t *, uint32_t);
 template <int NP>
 diag_kernel_t pick_diag(int nlw)
 {
@@ -454,7 +457,7 @@ int malcs_diag_plan(malcs_batch *b, int nlw, const std::vector<uint32_t> &pairs,
     MALCS_HIP(hipMalloc(&d.d_retry_list, (size_t)std::max<uint32_t>(acc, 1) * sizeof(uint32_t)));
     MALCS_HIP(hipMalloc(&d.d_retry_first, ncls * sizeof(uint32_t)));
     MALCS_HIP(hipMalloc(&d.d_retry_cap, ncls * sizeof(uint32_t)));
-    MALCS_HIP(hipMalloc(&d.d_retry_count, ncls * sizeof(uint32_t)));
+    MALCS_HIP(hipMalloc(&d.d_retry_count, 2 * ncls * sizeof(uint32_t)));   // two sets, used by alternate launches
     MALCS_HIP(hipMalloc(&d_tile_pid, tile_pid.size() * sizeof(uint32_t)));
     MALCS_HIP(hipMalloc(&d_tile_kc, tile_kc.size() * sizeof(uint32_t)));
     MALCS_HIP(hipMemcpyAsync(d.d_tile_off, tile_off.data(), (n_tiles + 1) * sizeof(uint32_t), hipMemcpyHostToDevice, st));
@@ -465,7 +468,7 @@ int malcs_diag_plan(malcs_batch *b, int nlw, const std::vector<uint32_t> &pairs,
         MALCS_HIP(hipMemcpyAsync(d.d_retry_first, first.data(), classes.size() * sizeof(uint32_t), hipMemcpyHostToDevice, st));
         MALCS_HIP(hipMemcpyAsync(d.d_retry_cap, cap.data(), classes.size() * sizeof(uint32_t), hipMemcpyHostToDevice, st));
     }
-    MALCS_HIP(hipMemsetAsync(d.d_retry_count, 0, ncls * sizeof(uint32_t), st));
+    MALCS_HIP(hipMemsetAsync(d.d_retry_count, 0, 2 * ncls * sizeof(uint32_t), st));
     const dim3 grid(max_rows, n_tiles), block(64);
     switch (b->n_planes) {
     case 2: hipLaunchKernelGGL(k_diag_layout<2>, grid, block, 0, st, b->d_planes, b->d_a_off, b->d_a_len, b->d_b_off, b->d_b_len, d_tile_pid, d_tile_kc, d.d_tile_off, d.d_tile_iters, nlw, d.d_rows); break;
@@ -479,12 +482,15 @@ int malcs_diag_plan(malcs_batch *b, int nlw, const std::vector<uint32_t> &pairs,
     return MALCS_OK;
 }
 
-int malcs_diag_launch(malcs_batch *b, bool reset_counters)
+// Launches the window kernel.  The retry counters exist twice: a launch appends through one set and zeroes
+// the other one for its successor (stream order makes that safe), which saves a memset per launch.
+// `advance` = false re-uses the current set without resetting it (timing loops over this kernel alone:
+// appends beyond a list's capacity are dropped by the kernel).
+int malcs_diag_launch(malcs_batch *b, bool advance)
 {
     diag_plan &d = b->diag;
     if (!d.nlw) return MALCS_OK;
     hipStream_t st = b->ctx->stream;
-    if (reset_counters && !d.retry.empty()) MALCS_HIP(hipMemsetAsync(d.d_retry_count, 0, d.retry.size() * sizeof(uint32_t), st));
     diag_kernel_t fn = nullptr;
     switch (b->n_planes) {
     case 2: fn = pick_diag<2>(d.nlw); break;
@@ -492,8 +498,12 @@ int malcs_diag_launch(malcs_batch *b, bool reset_counters)
     case 4: fn = pick_diag<4>(d.nlw); break;
     }
     if (!fn) { malcs_set_error("no window kernel for %d limbs and %d bit planes", d.nlw, b->n_planes); return MALCS_ERR_INTERNAL; }
+    const uint32_t ncls = (uint32_t)std::max<size_t>(d.retry.size(), 1);
+    if (ncls > 64) { malcs_set_error("too many retry classes"); return MALCS_ERR_INTERNAL; }
+    if (advance) d.parity ^= 1u;
+    uint32_t *cur = d.d_retry_count + d.parity * ncls, *next = d.d_retry_count + (d.parity ^ 1u) * ncls;
     hipLaunchKernelGGL(fn, dim3(d.n_tiles), dim3(64), 0, st, d.d_rows, d.d_tile_off, d.d_tile_iters, b->d_dist,
-                       d.d_retry_list, d.d_retry_first, d.d_retry_cap, d.d_retry_count);
+                       d.d_retry_list, d.d_retry_first, d.d_retry_cap, cur, next, advance ? ncls : 0u);
     MALCS_HIP(hipGetLastError());
     return MALCS_OK;
 }

@@ -155,7 +155,7 @@ k_llcs_bitpar(const uint32_t *__restrict__ planes,
 // kernel of malcs_diag.hip could not settle): a fixed grid, every wave takes slots until the list is
 // exhausted.  The count is read once, so every wave leaves the loop.
 template <int W, int NP, bool XL>
-__global__ void __launch_bounds__(256, MALCS_MINW)
+__global__ void __launch_bounds__(256, 6)          // the loop around the wave costs a few registers more
 k_llcs_bitpar_list(const uint32_t *__restrict__ planes,
                    const uint32_t *__restrict__ a_off, const uint32_t *__restrict__ a_len,
                    const uint32_t *__restrict__ b_off, const uint32_t *__restrict__ b_len,
@@ -467,7 +467,8 @@ int malcs_dist_launch(malcs_batch *b)
             const uint32_t ppw = 64u / (uint32_t)r.L;
             const uint32_t waves = std::min<uint32_t>((r.cap + ppw - 1u) / ppw, 1024u);
             hipLaunchKernelGGL(fn, dim3((waves + 3u) / 4u), dim3(256), 0, b->ctx->stream, b->d_planes, b->d_a_off, b->d_a_len,
-                               b->d_b_off, b->d_b_len, b->diag.d_retry_list, r.first, b->diag.d_retry_count + c, r.cap, logL, b->d_dist);
+                               b->d_b_off, b->d_b_len, b->diag.d_retry_list, r.first,
+                               b->diag.d_retry_count + b->diag.parity * std::max<size_t>(b->diag.retry.size(), 1) + c, r.cap, logL, b->d_dist);
             MALCS_HIP(hipGetLastError());
         }
     }

@@ -49,6 +49,7 @@ struct diag_plan {
     uint32_t *d_tile_iters = nullptr;    // column blocks of each tile
     uint32_t *d_retry_list = nullptr, *d_retry_first = nullptr, *d_retry_cap = nullptr, *d_retry_count = nullptr;
     std::vector<diag_retry> retry;
+    uint32_t parity = 0;                 // which of the two sets of retry counters the last launch used
 };
 
 struct malcs_batch {
@@ -79,7 +80,7 @@ int malcs_pack_launch(malcs_ctx *ctx, const uint8_t *d_syms, const uint64_t *d_s
 // pairs[i] goes to the window class; retry_class[i] indexes `classes` (its full-matrix launch class)
 int malcs_diag_plan(malcs_batch *b, int nlw, const std::vector<uint32_t> &pairs, const std::vector<uint8_t> &retry_class,
                     const std::vector<diag_retry> &classes);
-int malcs_diag_launch(malcs_batch *b, bool reset_counters);
+int malcs_diag_launch(malcs_batch *b, bool advance);
 void malcs_diag_release(malcs_batch *b);
 int malcs_diag_threshold(int nlw);
 

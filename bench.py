@@ -200,7 +200,7 @@ def main():
     kernel_ms = batch.time_dominant_kernel(args.steps) / args.steps
     if plan["window_pairs"]:
         kernel_cells = float(plan["window_cells"])
-        kernel_name = f"k_llcs_diag<{plan['window_limbs']},2>"
+        kernel_name = f"k_llcs_diag<{plan['window_limbs']},2,true>"
         algorithmic = (f"{OPS_PER_CELL} lane-op/cell x {kernel_cells:.4g} window cells/launch "
                        f"({32 * plan['window_limbs']} rows x text length, {plan['window_pairs']} pairs; "
                        f"{cells:.4g} full-matrix-equivalent cells)")
@@ -211,13 +211,11 @@ def main():
     achieved = kernel_cells * OPS_PER_CELL / (kernel_ms * 1e-3) / 1e12
 
     if rank == 0:
-        traffic = None
-        pmc = os.path.join(ROOT, "profiles", "r01_family1_pmc.json")
-        if os.path.exists(pmc):
+        traffic = None                                       # HBM bytes per launch of that kernel, PMC passes of this command
+        pmc = os.path.join(ROOT, "profiles", "r01_pmc.json")
+        if os.path.exists(pmc) and args.pairs == 100000:
             with open(pmc) as f:
-                rec = json.load(f)
-            if rec.get("pairs") == args.pairs:
-                traffic = rec.get("hbm_bytes_per_launch")
+                traffic = json.load(f)["kernels"].get(kernel_name, {}).get("hbm_bytes_per_launch")
         out = {
             "metric": "GCUPS (batched LCS edit distance, 1 kb windows)",
             "value": round(total_cells * args.steps / elapsed / 1e9, 1),
