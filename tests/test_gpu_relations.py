@@ -145,3 +145,32 @@ def test_extract_sequence_large(idx):
     assert len(variants) == rec["n_variants"]
     assert digest([[v.start, v.end, v.sequence] for v in variants]) == rec["canonical_sha256"]
     assert digest(to_hgvs(variants, a)) == rec["hgvs_sha256"]
+
+
+VARIANTS = load_golden("variants.json")
+
+
+def test_to_dot_matches_the_reference():
+    """Graphviz export (reference algebra/utils.py:20-62) over graphs built on the GPU, all label flavours."""
+    from algebra_amd.lcs import LCSgraph
+    from algebra_amd.utils import to_dot
+    from algebra_amd.variants import Variant
+    for rec in VARIANTS["to_dot"]:
+        if rec["variants"] is None:
+            graph = LCSgraph("", "")
+        else:
+            graph = LCSgraph.from_variant(rec["reference"], [Variant(*v) for v in rec["variants"]])
+        got = list(to_dot(rec["reference"], graph, labels=rec["labels"], hgvs=rec["hgvs"], atomics=rec["atomics"]))
+        assert got == rec["dot"], (rec["reference"], rec["variants"])
+
+
+def test_config1_plumbing():
+    """BASELINE config 1 in small: HGVS text -> parse_hgvs -> compare -> Relation, labels captured from the reference."""
+    from algebra_amd import compare
+    from algebra_amd.variants import parse_hgvs
+    case = VARIANTS["config1"]
+    reference = case["reference"]
+    for rec in case["pairs"] + case["hot_pairs"]:
+        lhs, rhs = parse_hgvs(rec["lhs_hgvs"], reference), parse_hgvs(rec["rhs_hgvs"], reference)
+        assert [[v.start, v.end, v.sequence] for v in lhs] == rec["lhs"]
+        assert compare(reference, lhs, rhs).value == rec["relation"], (rec["lhs_hgvs"], rec["rhs_hgvs"])
