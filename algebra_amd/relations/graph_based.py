@@ -43,6 +43,31 @@ def compare(reference, lhs, rhs):
     return Relation.OVERLAP
 
 
+def compare_batch(reference, lhs_graphs, rhs_graphs):
+    """[compare(reference, l, r) for l, r in zip(lhs_graphs, rhs_graphs)] with ONE batch of edit distances:
+    the pre-filters (:51-54) are evaluated on the host, every pair they leave undecided contributes its union
+    windows to a single GPU batch, and only pairs the distances cannot settle (:76-79) look at atoms."""
+    from ..lcs import edit_distance_batch
+    relations = [None] * len(lhs_graphs)
+    windows, owners = [], []
+    for k, (lhs, rhs) in enumerate(zip(lhs_graphs, rhs_graphs)):
+        if lhs.supremal == rhs.supremal:
+            relations[k] = Relation.EQUIVALENT
+        elif lhs.supremal.is_disjoint(rhs.supremal):
+            relations[k] = Relation.DISJOINT
+        else:
+            windows.append(union_windows(reference, lhs.supremal, rhs.supremal))
+            owners.append(k)
+    if windows:
+        for k, distance in zip(owners, edit_distance_batch(windows).tolist()):
+            lhs, rhs = lhs_graphs[k], rhs_graphs[k]
+            decided = from_distances(lhs.distance, rhs.distance, distance)
+            if decided is None:
+                decided = Relation.DISJOINT if lhs.is_disjoint(rhs) else Relation.OVERLAP
+            relations[k] = decided
+    return relations
+
+
 def are_equivalent(reference, lhs, rhs):
     """Check if two LCS graphs are equivalent."""
     return compare(reference, lhs, rhs) == Relation.EQUIVALENT

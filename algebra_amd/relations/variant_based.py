@@ -12,6 +12,15 @@ def compare(reference, lhs, rhs):
     return graph_based.compare(reference, LCSgraph.from_variant(reference, lhs), LCSgraph.from_variant(reference, rhs))
 
 
+def compare_batch(reference, lhs_alleles, rhs_alleles, offset=10):
+    """[compare(reference, l, r) for l, r in zip(lhs_alleles, rhs_alleles)], batched: all supremal graphs are
+    built in shared rounds of window widening (`LCSgraph.from_variant_batch`), all union-window distances in one
+    GPU batch.  This is the shape of BASELINE config 1 (many allele pairs against one reference)."""
+    n = len(lhs_alleles)
+    graphs = LCSgraph.from_variant_batch(reference, list(lhs_alleles) + list(rhs_alleles), offset)
+    return graph_based.compare_batch(reference, graphs[:n], graphs[n:])
+
+
 def are_equivalent(reference, lhs, rhs):
     """Check if two variants are equivalent."""
     return compare(reference, lhs, rhs) == Relation.EQUIVALENT

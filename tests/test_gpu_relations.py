@@ -174,3 +174,16 @@ def test_config1_plumbing():
         lhs, rhs = parse_hgvs(rec["lhs_hgvs"], reference), parse_hgvs(rec["rhs_hgvs"], reference)
         assert [[v.start, v.end, v.sequence] for v in lhs] == rec["lhs"]
         assert compare(reference, lhs, rhs).value == rec["relation"], (rec["lhs_hgvs"], rec["rhs_hgvs"])
+
+
+def test_config1_batched():
+    """The same pairs through compare_batch (shared widening rounds + one distance batch)."""
+    from algebra_amd.relations import compare_batch
+    from algebra_amd.variants import parse_hgvs
+    case = VARIANTS["config1"]
+    reference = case["reference"]
+    recs = case["pairs"] + case["hot_pairs"]
+    lhs = [parse_hgvs(r["lhs_hgvs"], reference) for r in recs]
+    rhs = [parse_hgvs(r["rhs_hgvs"], reference) for r in recs]
+    got = compare_batch(reference, lhs, rhs)
+    assert [g.value for g in got] == [r["relation"] for r in recs]

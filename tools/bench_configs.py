@@ -22,6 +22,28 @@ def run_pairs(name, pairs, reps=2):
     bt.close()
 
 which = sys.argv[1:] or ["c2", "c3", "c5"]
+if "c1" in which:
+    # BASELINE config 1 (plumbing): random.Random(1)-style stream, 1 000 bp reference, 10 000 pairs of alleles from
+    # random_variants(p=0.002), serialised to HGVS, re-parsed, compared
+    import random
+    from algebra_amd.relations import compare, compare_batch
+    from algebra_amd.utils import random_sequence, random_variants
+    from algebra_amd.variants import parse_hgvs, to_hgvs as allele_hgvs
+    random.seed(1)
+    reference = random_sequence(1000, 1000)
+    text = [(allele_hgvs(list(random_variants(reference, p=0.002)), reference), allele_hgvs(list(random_variants(reference, p=0.002)), reference))
+            for _ in range(10000)]
+    t0 = time.time()
+    lhs = [parse_hgvs(a, reference) for a, _ in text]; rhs = [parse_hgvs(b, reference) for _, b in text]
+    t1 = time.time()
+    rel = compare_batch(reference, lhs, rhs)
+    t2 = time.time()
+    one = [compare(reference, l, r) for l, r in zip(lhs[:300], rhs[:300])]
+    t3 = time.time()
+    assert one == rel[:300]
+    from collections import Counter
+    print(f"C1 10000 allele pairs: parse {1e3*(t1-t0):.0f} ms, compare_batch {1e3*(t2-t1):.0f} ms -> {10000/(t2-t0):.0f} relations/s end to end; "
+          f"one compare() at a time: {1e3*(t3-t2)/300:.2f} ms/pair; {dict(Counter(r.value for r in rel))}", flush=True)
 if "c2" in which:
     n = 100000
     data = gen.c2_batch(n)
