@@ -288,8 +288,52 @@ class LCSgraph:
         return lhs & rhs, lhs | rhs
 
     def is_disjoint(self, other):
-        """Are two LCS graphs disjoint (reference lcs_graph.py:226-228)."""
-        return self.uniq_atomics().isdisjoint(other.uniq_atomics())
+        """Are two LCS graphs disjoint (reference lcs_graph.py:226-228).  For library-built DNA graphs the
+        atoms are compared as per-position bit masks over the edge arrays, which keeps
+        graphs with 1e5+ edges away from Python sets; the result is the same."""
+        mine, theirs = self._atom_masks(), other._atom_masks() if isinstance(other, LCSgraph) else None
+        if mine is None or theirs is None:
+            return self.uniq_atomics().isdisjoint(other.uniq_atomics())
+        (lo_a, mask_a), (lo_b, mask_b) = mine, theirs
+        lo = max(lo_a, lo_b)
+        hi = min(lo_a + len(mask_a), lo_b + len(mask_b))
+        if hi <= lo:
+            return True
+        return not np.any(mask_a[lo - lo_a:hi - lo_a] & mask_b[lo - lo_b:hi - lo_b])
+
+    _ATOM_BITS = {"A": 1, "C": 2, "G": 3, "T": 4}          # bit 0: the deletion atom (idx, "")
+
+    def _atom_masks(self):
+        """(first position, uint8 mask per position) with bit 0 = (pos, "") and bits 1-4 = (pos, A/C/G/T) in
+        uniq_atomics(); None when the graph was put together by hand or uses other symbols."""
+        cached = self.__dict__.get("_atoms")
+        if cached is not None:
+            return cached or None
+        result = self.__dict__.get("_result")
+        observed = self.__dict__.get("_observed", "")
+        if result is None or not set(observed) <= set(self._ATOM_BITS):
+            self.__dict__["_atoms"] = ()
+            return None
+        edges = result[0].edges(result[1])
+        lo = self.supremal.start
+        size = self.supremal.end - lo + 1
+        masks = np.zeros(size, dtype=np.uint8)
+        if len(edges):
+            start, end = edges[:, 2] - lo, edges[:, 3] - lo
+            codes = np.frombuffer(observed.encode("ascii"), dtype=np.uint8)
+            span = np.zeros(size + 2, dtype=np.int32)
+            np.add.at(span, start, 1)
+            np.add.at(span, end, -1)                              # (idx, "") for idx in [start, end)
+            masks |= (np.cumsum(span)[:size] > 0).astype(np.uint8)
+            for ch, bit in self._ATOM_BITS.items():
+                count = np.concatenate(([0], np.cumsum(codes == ord(ch))))
+                present = count[edges[:, 5]] > count[edges[:, 4]]   # ch in observed[obs_from:obs_to]
+                span[:] = 0
+                np.add.at(span, start[present], 1)
+                np.add.at(span, end[present] + 1, -1)             # (idx, ch) for idx in [start, end]
+                masks |= (np.cumsum(span)[:size] > 0).astype(np.uint8) << bit
+        self.__dict__["_atoms"] = (lo, masks)
+        return self.__dict__["_atoms"]
 
 
 def trim(lhs, rhs):

@@ -133,11 +133,14 @@ def extra_configs(ctx, _native, gen):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=50)
-    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--steps", type=int, default=200)
+    ap.add_argument("--warmup", type=int, default=10)
     ap.add_argument("--pairs", type=int, default=100000)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extra", action="store_true", help="skip the secondary configs (graphs, relation matrix)")
+    ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl = RCCL; gloo only to rehearse the "
+                                                      "multi-rank path on a box with fewer GPUs than ranks)")
+    ap.add_argument("--share-device", action="store_true", help="rehearsal: all ranks use GPU 0")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -148,11 +151,18 @@ def main():
     os.environ.setdefault("MALCS_DEVICE", str(local_rank))
 
     import torch
+    if args.share_device:
+        local_rank = 0
+        os.environ["MALCS_DEVICE"] = "0"
     torch.cuda.set_device(local_rank)
     dist = None
     if world > 1:
         import torch.distributed as dist
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        if args.backend == "nccl":
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        else:
+            dist.init_process_group(args.backend)
+    reduce_device = "cuda" if args.backend == "nccl" else "cpu"
 
     import gen
     from algebra_amd import _native
@@ -179,10 +189,10 @@ def main():
     fence()
     elapsed = time.perf_counter() - t0
     if dist is not None:
-        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        t = torch.tensor([elapsed], dtype=torch.float64, device=reduce_device)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
-        c = torch.tensor([cells], dtype=torch.float64, device="cuda")
+        c = torch.tensor([cells], dtype=torch.float64, device=reduce_device)
         dist.all_reduce(c, op=dist.ReduceOp.SUM)
         total_cells = float(c.item())
     else:

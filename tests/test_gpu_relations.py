@@ -187,3 +187,31 @@ def test_config1_batched():
     rhs = [parse_hgvs(r["rhs_hgvs"], reference) for r in recs]
     got = compare_batch(reference, lhs, rhs)
     assert [g.value for g in got] == [r["relation"] for r in recs]
+
+
+def test_atom_masks_equal_atom_sets():
+    """LCSgraph.is_disjoint over per-position bit masks (edge arrays) against the set-based definition
+    (reference lcs_graph.py:207-228), on clustered variants where all three outcomes occur."""
+    from algebra_amd.lcs import LCSgraph
+    from algebra_amd.variants import Variant
+    bits = {"": 0, "A": 1, "C": 2, "G": 3, "T": 4}
+    seen = set()
+    for case in SEQS["matrices"]:
+        graphs = LCSgraph.from_variant_batch(case["reference"], [[Variant(*v)] for v in case["variants"]])
+        for g in graphs:
+            lo, masks = g._atom_masks()
+            want = {(idx, ch) for idx, ch in g.uniq_atomics()}
+            got = {(lo + int(k), ch) for k in range(len(masks)) for ch, b in bits.items() if masks[k] >> b & 1}
+            assert got == want
+        for i in range(0, len(graphs), 3):
+            for j in range(len(graphs)):
+                want = graphs[i].uniq_atomics().isdisjoint(graphs[j].uniq_atomics())
+                assert graphs[i].is_disjoint(graphs[j]) == want
+                seen.add(want)
+    assert seen == {True, False}
+    # larger graphs: tandem repeats with thousands of edges
+    rs = np.random.RandomState(77)
+    a, b = gen.tandem_pair(rs, 600, 4)
+    c = a[:300] + "ACGT" + a[300:]
+    g1, g2 = LCSgraph.batch([(a, b), (a, c)])
+    assert g1.is_disjoint(g2) == g1.uniq_atomics().isdisjoint(g2.uniq_atomics())
