@@ -13,6 +13,7 @@
 #include <algorithm>
 #include <atomic>
 #include <chrono>
+#include <deque>
 #include <cstring>
 #include <new>
 #include <thread>
@@ -47,7 +48,17 @@ struct pair_graph {
 };
 
 // ---- events -> runs in the reference's emission order -------------------------------------------
-bool runs_from_events(std::vector<event> &ev, int64_t m, int64_t n, std::vector<run> &out)
+// a pair's events: a slice of the chunk buffer they came home in (sorted in place)
+struct event_span {
+    event *p = nullptr;
+    size_t n = 0;
+    event *begin() const { return p; }
+    event *end() const { return p + n; }
+    size_t size() const { return n; }
+    const event &operator[](size_t i) const { return p[i]; }
+};
+
+bool runs_from_events(event_span ev, int64_t m, int64_t n, std::vector<run> &out)
 {
     // starts and ends alternate along every diagonal
     std::sort(ev.begin(), ev.end(), [](const event &a, const event &b) {
@@ -96,6 +107,10 @@ struct builder {
     std::vector<int64_t> row, col, length, wlen, incoming;
     std::vector<std::vector<gedge>> out;
 
+    void reserve(size_t k)
+    {
+        row.reserve(k); col.reserve(k); length.reserve(k); wlen.reserve(k); incoming.reserve(k); out.reserve(k);
+    }
     int32_t add(int64_t r, int64_t c, int64_t l)
     {
         row.push_back(r); col.push_back(c); length.push_back(l); wlen.push_back(l); incoming.push_back(0);
@@ -107,6 +122,7 @@ struct builder {
 void build_graph(int64_t m, int64_t n, int64_t shift, const std::vector<run> &runs, int64_t n_levels, pair_graph &G)
 {
     builder B;
+    B.reserve(runs.size() * 2 + 8);
     int32_t source, sink;
     const bool degenerate = runs.empty() || n_levels == 0;
     if (degenerate) {                                                    // :370-377
@@ -119,22 +135,27 @@ void build_graph(int64_t m, int64_t n, int64_t shift, const std::vector<run> &ru
             G.supremal[0] = shift; G.supremal[1] = shift + m; G.supremal[2] = 0; G.supremal[3] = n;
         }
     } else {
-        std::vector<std::vector<int32_t>> levels((size_t)n_levels + 1);
-        for (const run &r : runs) levels[(size_t)r.level].push_back(B.add(r.row + shift, r.col + shift, r.len));
-
-        const int32_t last = levels[(size_t)n_levels - 1].back();        // :379-385
+        // Level lists: the runs arrive sorted by level, so level L is a contiguous range of node ids; only two
+        // lists are alive at a time (the level being emptied and the one below it), kept in two reused vectors
+        // -- the reference's list of ~LLCS lists would cost an allocation per level here.
+        for (const run &r : runs) B.add(r.row + shift, r.col + shift, r.len);      // node id == run index
+        size_t unread = runs.size();                                     // runs [0, unread) are not in a list yet
+        const int32_t last = (int32_t)runs.size() - 1;                   // last node of the last level, :379-385
         if (B.row[last] + B.length[last] == m + shift && B.col[last] + B.length[last] == n + shift) {
-            levels[(size_t)n_levels - 1].pop_back();
+            unread--;                                                    // popped from its level
             sink = B.add(B.row[last], B.col[last], B.length[last] + 1);
         } else {
             sink = B.add(m + shift, n + shift, 1);
         }
-        levels[(size_t)n_levels].push_back(sink);
+        std::vector<int32_t> cur{sink}, below;
 
         int64_t max_sink = 0;
         for (int64_t depth = n_levels + 1; depth > 1; depth--) {         // depth == len_lcs_nodes, :389
-            std::vector<int32_t> &cur = levels[(size_t)depth - 1];
-            std::vector<int32_t> &below = levels[(size_t)depth - 2];
+            size_t first = unread;
+            while (first > 0 && runs[first - 1].level == depth - 2) first--;
+            below.clear();
+            for (size_t i = first; i < unread; i++) below.push_back((int32_t)i);
+            unread = first;
             for (size_t qi = 0; qi < cur.size(); qi++) {                 // pop(0) in order, :390-391
                 const int32_t node = cur[qi];
                 if (node != sink && B.out[node].empty()) continue;       // :393-394
@@ -167,10 +188,10 @@ void build_graph(int64_t m, int64_t n, int64_t shift, const std::vector<run> &ru
                     below.insert(below.begin() + (std::ptrdiff_t)idx_parent, node);
                 }
             }
-            std::vector<int32_t>().swap(cur);                            // :425
+            cur.swap(below);                                             // :425
         }
 
-        std::vector<int32_t> &l0 = levels[0];                            // :428-432
+        std::vector<int32_t> &l0 = cur;                                  // level 0, :428-432
         size_t first = 0;
         source = l0[0];
         if (B.row[source] == shift && B.col[source] == shift) first = 1;
@@ -362,7 +383,8 @@ static int graph_batch(malcs_batch *b, const int64_t *shift, const int64_t *max_
     hipStream_t st = ctx->stream;
     const uint64_t N = b->n_pairs;
     out->g.resize(N);
-    std::vector<std::vector<event>> pair_events(N);
+    std::vector<event_span> pair_events(N);
+    std::deque<std::vector<event>> event_store;          // one buffer per chunk, alive until the graphs are built
     std::vector<uint8_t> has_runs(N, 0);
 
     // exact distances first (kernel family 1): they decide max_distance, the band and the event budget
@@ -530,12 +552,11 @@ static int graph_batch(malcs_batch *b, const int64_t *shift, const int64_t *max_
                 MALCS_HIP(hipMemcpyAsync(d_outoff.p, out_off.data(), cnt * 8ull, hipMemcpyHostToDevice, st));
                 rc = malcs_graph_launch_compact(ctx, d_events.p, d_evoff.p, d_evcnt.p, d_outoff.p, cnt, d_packed.p);
                 if (rc) return rc;
-                std::vector<event> host_ev(packed);
+                event_store.emplace_back(packed);
+                std::vector<event> &host_ev = event_store.back();
                 if (packed) MALCS_HIP(hipMemcpyAsync(host_ev.data(), d_packed.p, packed * sizeof(event), hipMemcpyDeviceToHost, st));
                 MALCS_HIP(hipStreamSynchronize(st));
-                for (uint32_t s = 0; s < cnt; s++)
-                    pair_events[work[s]].assign(host_ev.begin() + (std::ptrdiff_t)out_off[s],
-                                                host_ev.begin() + (std::ptrdiff_t)(out_off[s] + ev_cnt[s]));
+                for (uint32_t s = 0; s < cnt; s++) { pair_events[work[s]].p = host_ev.data() + out_off[s]; pair_events[work[s]].n = ev_cnt[s]; }
                 break;
             }
         }
@@ -547,6 +568,8 @@ static int graph_batch(malcs_batch *b, const int64_t *shift, const int64_t *max_
     const double t0 = now_ms();
     std::atomic<uint64_t> next(0);
     std::atomic<int> failed(0);
+    std::atomic<uint64_t> ns_runs(0), ns_build(0);
+    const bool trace = getenv("MALCS_TRACE") != nullptr;
     auto worker = [&]() {
         std::vector<run> runs;
         for (;;) {
@@ -556,7 +579,9 @@ static int graph_batch(malcs_batch *b, const int64_t *shift, const int64_t *max_
             if (G.status != MALCS_PAIR_OK) continue;
             const int64_t m = b->a_len[i], n = b->b_len[i];
             runs.clear();
+            const double ta = trace ? now_ms() : 0;
             if (has_runs[i] && !runs_from_events(pair_events[i], m, n, runs)) { failed.store(1); continue; }
+            const double tb = trace ? now_ms() : 0;
             const int64_t llcs = (m + n - G.distance) / 2;
             G.n_levels = runs.empty() ? (std::min(m, n) > 0 ? 1 : 0) : llcs;
             const int64_t sh = shift ? shift[i] : 0;
@@ -568,6 +593,7 @@ static int graph_batch(malcs_batch *b, const int64_t *shift, const int64_t *max_
             }
             if (failed.load()) continue;
             build_graph(m, n, sh, runs, runs.empty() ? 0 : llcs, G);
+            if (trace) { ns_runs += (uint64_t)((tb - ta) * 1e6); ns_build += (uint64_t)((now_ms() - tb) * 1e6); }
         }
     };
     unsigned nt = std::min<unsigned>(16u, std::max(1u, std::thread::hardware_concurrency()));
@@ -577,6 +603,8 @@ static int graph_batch(malcs_batch *b, const int64_t *shift, const int64_t *max_
     worker();
     for (std::thread &t : pool) t.join();
     out->timing[2] = (float)(now_ms() - t0);
+    if (trace) fprintf(stderr, "malcs host build: %llu pairs, %u threads, wall %.2f ms; summed over threads: events->runs %.2f ms, build_graph %.2f ms\n",
+                       (unsigned long long)N, nt, out->timing[2], ns_runs.load() / 1e6, ns_build.load() / 1e6);
     if (failed.load()) { malcs_set_error("device events do not form runs (internal error)"); return MALCS_ERR_INTERNAL; }
     return MALCS_OK;
 }
