@@ -51,6 +51,7 @@ def _load():
         "malcs_batch_plan_info": (c.c_int, [vp, P(c.c_uint64)]),
         "malcs_edit_distance_batch": (c.c_int, [vp, vp, u64, vp, vp, vp, vp, u64, c.c_int, vp]),
         "malcs_lcs_graph_batch": (c.c_int, [vp, vp, vp, P(vp)]),
+        "malcs_lcs_nodes_batch": (c.c_int, [vp, vp, vp, P(vp)]),
         "malcs_graphs_destroy": (c.c_int, [vp]),
         "malcs_graphs_counts": (c.c_int, [vp, vp]),
         "malcs_graphs_status": (c.c_int, [vp, vp, vp]),
@@ -197,7 +198,12 @@ class Batch:
         keys = ("window_pairs", "window_limbs", "window_threshold", "window_cells", "full_cells", "full_classes")
         return dict(zip(keys, (int(x) for x in info)))
 
-    def graphs(self, shift=None, max_distance=None):
+    def lcs_nodes(self, shift=None, max_distance=None):
+        """_lcs_nodes(reference_i, observed_i, shift_i, max_distance_i) for every pair: the reference's
+        complete level lists (Graphs handle with runs only)."""
+        return self.graphs(shift, max_distance, _entry=lib.malcs_lcs_nodes_batch)
+
+    def graphs(self, shift=None, max_distance=None, _entry=None):
         """LCSgraph(reference_i, observed_i, shift_i, max_distance_i) for every pair."""
         sh = md = None
         if shift is not None:
@@ -205,8 +211,8 @@ class Batch:
         if max_distance is not None:
             md = np.ascontiguousarray(max_distance, dtype=np.int64)
         handle = ctypes.c_void_p()
-        check(lib.malcs_lcs_graph_batch(self.handle, ptr(sh) if sh is not None else None,
-                                        ptr(md) if md is not None else None, ctypes.byref(handle)))
+        check((_entry or lib.malcs_lcs_graph_batch)(self.handle, ptr(sh) if sh is not None else None,
+                                                     ptr(md) if md is not None else None, ctypes.byref(handle)))
         return Graphs(handle, self.n_pairs)
 
 

@@ -29,6 +29,9 @@ int malcs_graph_launch_reach(malcs_batch *b, int W, int logL, bool band, const u
 int malcs_graph_launch_compact(malcs_ctx *ctx, const void *d_events, const uint64_t *d_ev_off, const uint32_t *d_ev_n,
                                const uint64_t *d_out_off, uint32_t count, void *d_out);
 
+int malcs_sweep_runs(malcs_batch *b, const std::vector<uint32_t> &work, const int32_t *dist,
+                     std::vector<uint32_t> &out_runs, std::vector<uint64_t> &out_first);
+
 namespace {
 
 struct event { uint32_t row, col, level, kind; };      // kind 0 = run ends in (row, col); 1 = run starts in (row, col)
@@ -58,24 +61,10 @@ struct event_span {
     const event &operator[](size_t i) const { return p[i]; }
 };
 
-bool runs_from_events(event_span ev, int64_t m, int64_t n, std::vector<run> &out)
+// the reference's emission order inside a level: by sweep iteration, then diagonals below
+// delta ascending, above delta descending, delta itself last, then along the diagonal
+void order_runs(std::vector<run> &out, int64_t m, int64_t n)
 {
-    // starts and ends alternate along every diagonal
-    std::sort(ev.begin(), ev.end(), [](const event &a, const event &b) {
-        const int64_t da = (int64_t)a.col - a.row, db = (int64_t)b.col - b.row;
-        if (da != db) return da < db;
-        if (a.row != b.row) return a.row < b.row;
-        return a.kind > b.kind;                      // a start sorts before the end of the same cell
-    });
-    if (ev.size() % 2) return false;
-    out.clear();
-    out.reserve(ev.size() / 2);
-    for (size_t i = 0; i < ev.size(); i += 2) {
-        const event &s = ev[i], &e = ev[i + 1];
-        if (s.kind != 1 || e.kind != 0) return false;
-        if ((int64_t)s.col - s.row != (int64_t)e.col - e.row || e.row < s.row) return false;
-        out.push_back({s.row, s.col, (int64_t)e.row - s.row + 1, e.level});
-    }
     const int64_t delta = n - m, adelta = delta < 0 ? -delta : delta;
     struct keyed { int64_t level, it, grp, dk, row; run r; };
     std::vector<keyed> k;
@@ -96,6 +85,27 @@ bool runs_from_events(event_span ev, int64_t m, int64_t n, std::vector<run> &out
         return a.row < b.row;
     });
     for (size_t i = 0; i < k.size(); i++) out[i] = k[i].r;
+}
+
+bool runs_from_events(event_span ev, int64_t m, int64_t n, std::vector<run> &out)
+{
+    // starts and ends alternate along every diagonal
+    std::sort(ev.begin(), ev.end(), [](const event &a, const event &b) {
+        const int64_t da = (int64_t)a.col - a.row, db = (int64_t)b.col - b.row;
+        if (da != db) return da < db;
+        if (a.row != b.row) return a.row < b.row;
+        return a.kind > b.kind;                      // a start sorts before the end of the same cell
+    });
+    if (ev.size() % 2) return false;
+    out.clear();
+    out.reserve(ev.size() / 2);
+    for (size_t i = 0; i < ev.size(); i += 2) {
+        const event &s = ev[i], &e = ev[i + 1];
+        if (s.kind != 1 || e.kind != 0) return false;
+        if ((int64_t)s.col - s.row != (int64_t)e.col - e.row || e.row < s.row) return false;
+        out.push_back({s.row, s.col, (int64_t)e.row - s.row + 1, e.level});
+    }
+    order_runs(out, m, n);
     return true;
 }
 
@@ -609,7 +619,77 @@ static int graph_batch(malcs_batch *b, const int64_t *shift, const int64_t *max_
     return MALCS_OK;
 }
 
+// _lcs_nodes with the reference's complete level lists: distances (family 1), then the sweep kernel
+static int nodes_batch(malcs_batch *b, const int64_t *shift, const int64_t *max_distance, malcs_graphs *out)
+{
+    hipStream_t st = b->ctx->stream;
+    const uint64_t N = b->n_pairs;
+    out->g.resize(N);
+    std::vector<int32_t> dist(N);
+    if (N) {
+        int rc = malcs_dist_launch(b);
+        if (rc) return rc;
+        MALCS_HIP(hipMemcpyAsync(dist.data(), b->d_dist, N * 4ull, hipMemcpyDeviceToHost, st));
+        MALCS_HIP(hipStreamSynchronize(st));
+    }
+    std::vector<uint32_t> work;
+    for (uint64_t i = 0; i < N; i++) {
+        pair_graph &G = out->g[i];
+        G.distance = dist[i];
+        const int64_t md = max_distance ? max_distance[i] : 0;
+        if (md && G.distance > md) { G.status = MALCS_PAIR_MAX_DISTANCE_EXCEEDED; continue; }   // :345-346
+        if (b->a_len[i] == 0 || b->b_len[i] == 0) continue;                                     // no level lists at all, :319
+        work.push_back((uint32_t)i);
+    }
+    std::vector<uint32_t> flat;
+    std::vector<uint64_t> first;
+    if (!work.empty()) {
+        int rc = malcs_sweep_runs(b, work, dist.data(), flat, first);
+        if (rc) return rc;
+    }
+    std::vector<run> runs;
+    for (size_t s = 0; s < work.size(); s++) {
+        const uint32_t i = work[s];
+        pair_graph &G = out->g[i];
+        const int64_t m = b->a_len[i], n = b->b_len[i], sh = shift ? shift[i] : 0;
+        runs.clear();
+        int64_t top = 0;                                                  // max_lcs_pos, :295,:312
+        for (uint64_t r = first[s]; r < first[s + 1]; r++) {
+            runs.push_back({flat[4 * r], flat[4 * r + 1], flat[4 * r + 2], flat[4 * r + 3]});
+            top = std::max<int64_t>(top, flat[4 * r + 3]);
+        }
+        order_runs(runs, m, n);
+        G.n_levels = top + 1;                                             // lcs_nodes[:max_lcs_pos + 1], :348
+        G.runs.resize(runs.size() * 4);
+        for (size_t r = 0; r < runs.size(); r++) {
+            G.runs[4 * r] = runs[r].row + sh; G.runs[4 * r + 1] = runs[r].col + sh;
+            G.runs[4 * r + 2] = runs[r].len; G.runs[4 * r + 3] = runs[r].level;
+        }
+    }
+    return MALCS_OK;
+}
+
 extern "C" {
+
+int malcs_lcs_nodes_batch(malcs_batch *b, const int64_t *shift, const int64_t *max_distance, malcs_graphs **graphs)
+{
+    if (!graphs) { malcs_set_error("graphs is NULL"); return MALCS_ERR_ARG; }
+    *graphs = nullptr;
+    if (!b) { malcs_set_error("batch is NULL"); return MALCS_ERR_ARG; }
+    MALCS_HIP(hipSetDevice(b->ctx->device));
+    malcs_graphs *g = new (std::nothrow) malcs_graphs();
+    if (!g) { malcs_set_error("out of host memory"); return MALCS_ERR_NOMEM; }
+    int rc;
+    try {
+        rc = nodes_batch(b, shift, max_distance, g);
+    } catch (const std::bad_alloc &) {
+        malcs_set_error("out of host memory");
+        rc = MALCS_ERR_NOMEM;
+    }
+    if (rc) { delete g; return rc; }
+    *graphs = g;
+    return MALCS_OK;
+}
 
 int malcs_lcs_graph_batch(malcs_batch *b, const int64_t *shift, const int64_t *max_distance, malcs_graphs **graphs)
 {

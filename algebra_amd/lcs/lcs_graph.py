@@ -367,17 +367,16 @@ def _common_prefix(lhs, rhs, limit):
 
 
 def _lcs_nodes(reference, observed, shift=0, max_distance=None):
-    """Distance and level-bucketed match runs (reference lcs_graph.py:238-348).
-
-    The device returns the runs that lie on some minimal alignment, in the reference's order;
-    the reference additionally lists runs its sweep walked over that `_build_graph` then discards
-    (SURVEY 8(a) P3), so the lists here are the sub-lists of the reference's that matter.
+    """Distance and level-bucketed match runs (reference lcs_graph.py:238-348): the lists the reference's
+    sweep fills, in its order, including the runs off every minimal alignment (kernel k_lcs_sweep).
+    `LCSgraph.__init__` does not come through here: the library builds the graph from the runs that
+    `_build_graph` keeps.
     """
     ctx = _native.default_context()
     syms, a_off, a_len, b_off, b_len, n_symbols = encode_pairs([(reference, observed)])
     batch = _native.Batch(ctx, syms, a_off, a_len, b_off, b_len, n_symbols)
     try:
-        res = batch.graphs(np.array([shift], dtype=np.int64), np.array([int(max_distance or 0)], dtype=np.int64))
+        res = batch.lcs_nodes(np.array([shift], dtype=np.int64), np.array([int(max_distance or 0)], dtype=np.int64))
     finally:
         batch.close()
     try:

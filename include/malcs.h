@@ -129,6 +129,13 @@ int malcs_edit_distance_batch(malcs_ctx *ctx, const uint8_t *syms, uint64_t n_sy
 int malcs_lcs_graph_batch(malcs_batch *batch, const int64_t *shift, const int64_t *max_distance,
                           malcs_graphs **graphs);
 int malcs_graphs_destroy(malcs_graphs *graphs);
+/* Stands in for _lcs_nodes(reference, observed, shift, max_distance) (algebra/lcs/lcs_graph.py:238-348) called on
+ * its own: the distance and the level lists exactly as the reference's sweep fills them, i.e. with the runs it
+ * walks over that lie on no minimal alignment as well (its tests pin them, tests/lcs/test_lcs_graph.py:20-51;
+ * _build_graph discards them, which is why malcs_lcs_graph_batch does not compute them).  The returned handle
+ * holds status, distance, n_levels (= len of the reference's list) and runs only; nodes and edges are empty. */
+int malcs_lcs_nodes_batch(malcs_batch *batch, const int64_t *shift, const int64_t *max_distance,
+                          malcs_graphs **graphs);
 /* per-pair sizes: counts[4*i + {0,1,2,3}] = {n_runs, n_levels, n_nodes, n_edges} */
 int malcs_graphs_counts(const malcs_graphs *graphs, int64_t *counts);
 int malcs_graphs_status(const malcs_graphs *graphs, int32_t *status, int64_t *distance);

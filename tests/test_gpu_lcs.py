@@ -290,15 +290,78 @@ def test_graph_arrays_vs_oracle(native):
 
 
 def test_lcs_nodes_facade(native):
+    """_lcs_nodes as the reference's test reads it (tests/lcs/test_lcs_graph.py:20-51): exact ordered
+    level lists, off-path runs and empty levels included."""
+    from algebra_amd.lcs import LCSgraph
     from algebra_amd.lcs.lcs_graph import _lcs_nodes
-    for a, b in (("AA", "ACA"), ("ACA", "AA"), ("CTCGGCATTA", "GGCTGGCTGT"), ("TTT", "TTTTAT"), ("", "")):
-        rec = next(r for r in REF["lcs"] if r["reference"] == a and r["observed"] == b and r["shift"] == 0)
-        distance, levels = _lcs_nodes(a, b)
-        assert distance == rec["graph"]["distance"]
-        assert distance == len(a) - len(levels) + len(b) - len(levels)      # reference test :50
-        for got, want in zip(levels, rec["levels"]):
-            it = iter(want)
-            assert all([n.row, n.col, n.length] in it for n in got)
+    assert _lcs_nodes("", "") == (0, [])
+    assert _lcs_nodes("A", "C") == (2, [[]])
+    assert _lcs_nodes("ACGT", "") == (4, [])
+    assert _lcs_nodes("AA", "ACA") == (1, [[LCSgraph.Node(0, 0, 1)], [LCSgraph.Node(1, 2, 1)]])
+    for rec in REF["lcs"][::3]:
+        a, b = rec["reference"], rec["observed"]
+        distance, levels = _lcs_nodes(a, b, rec["shift"])
+        assert distance == rec["edit_distance"]
+        got = [[[n.row, n.col, n.length] for n in level] for level in levels]
+        if "levels" in rec:
+            assert got == rec["levels"], (a, b)
+        else:
+            assert digest(got) == rec["levels_sha256"]
+        if levels and any(levels):
+            assert distance == len(a) - len(levels) + len(b) - len(levels)      # reference test :50
+
+
+def lcs_nodes_batch(native, cases):
+    from algebra_amd.lcs.encoding import encode_pairs
+    syms, a_off, a_len, b_off, b_len, n_symbols = encode_pairs([(c["reference"], c["observed"]) for c in cases])
+    batch = native.Batch(native.default_context(), syms, a_off, a_len, b_off, b_len, n_symbols)
+    res = batch.lcs_nodes(np.array([c["shift"] for c in cases], np.int64))
+    batch.close()
+    out = []
+    for i in range(len(cases)):
+        levels = [[] for _ in range(int(res.counts[i, 1]))]
+        for row, col, length, level in res.runs(i).tolist():
+            levels[level].append([row, col, length])
+        out.append((int(res.distance[i]), levels))
+    assert not res.counts[:, 2:].any()                 # runs only: no graph in this handle
+    res.close()
+    return out
+
+
+def test_lcs_nodes_exact_level_lists(native):
+    """malcs_lcs_nodes_batch against every level list captured from the reference (880 pairs)."""
+    cases = REF["lcs"] + SMALL["lcs"] + MEDIUM["lcs"]
+    for rec, (distance, levels) in zip(cases, lcs_nodes_batch(native, cases)):
+        assert distance == rec["edit_distance"]
+        if "levels" in rec:
+            assert levels == rec["levels"], (rec["reference"], rec["observed"], rec["shift"])
+        else:
+            assert len(levels) == rec["n_levels"] and digest(levels) == rec["levels_sha256"], rec.get("name")
+
+
+def test_lcs_nodes_vs_oracle(native):
+    """Seeded pairs beyond the fixtures' sizes (word and block boundaries, 1..9 symbols, divergent pairs whose
+    diagonals do not fit LDS) against the oracle's restatement of the sweep."""
+    from oracle import oracle as O
+    rs = np.random.RandomState(4242)
+    cases = []
+    for _ in range(160):
+        kind = ["random", "indel", "sparse", "tandem"][rs.randint(0, 4)]
+        a, b = gen.pair_of_kind(rs, kind, int(rs.randint(1, 700)), "ACGTNRYKM"[:rs.randint(1, 10)])
+        cases.append({"reference": a, "observed": b, "shift": int(rs.randint(0, 9))})
+    for m in (31, 32, 33, 63, 64, 65, 1000, 1024, 1025):
+        a, b = gen.pair_of_kind(rs, "indel", m, "ACGT")
+        cases.append({"reference": a, "observed": b, "shift": 0})
+        cases.append({"reference": a, "observed": a[: m // 2], "shift": 3})
+    a = "".join(rs.choice(list("AC"), 9000))
+    b = "".join(rs.choice(list("GT"), 9100))
+    cases.append({"reference": a, "observed": b, "shift": 0})              # 18 100 diagonals: FR in HBM, no matches
+    a, b = gen.pair_of_kind(rs, "random", 3000, "ACGT")
+    cases.append({"reference": a, "observed": b, "shift": 0})              # random 3 kb pair, ~2 000 diagonals, ~1e6 runs
+    for c, (distance, levels) in zip(cases, lcs_nodes_batch(native, cases)):
+        ref = O.lcs_graph(c["reference"], c["observed"], c["shift"])
+        assert distance == ref.distance
+        assert levels == [[list(t) for t in lvl] for lvl in ref.level_lists()], (len(c["reference"]), len(c["observed"]))
 
 
 def test_max_distance(native):
