@@ -32,6 +32,9 @@ int malcs_graph_launch_compact(malcs_ctx *ctx, const void *d_events, const uint6
 int malcs_sweep_runs(malcs_batch *b, const std::vector<uint32_t> &work, const int32_t *dist,
                      std::vector<uint32_t> &out_runs, std::vector<uint64_t> &out_first);
 
+int malcs_sweep_optimal_runs(malcs_batch *b, const std::vector<uint32_t> &work, const int32_t *dist,
+                             std::vector<uint32_t> &out_runs, std::vector<uint64_t> &out_first, float *ms);
+
 namespace {
 
 struct event { uint32_t row, col, level, kind; };      // kind 0 = run ends in (row, col); 1 = run starts in (row, col)
@@ -411,6 +414,10 @@ static int graph_batch(malcs_batch *b, const int64_t *shift, const int64_t *max_
     const int band_wmax = malcs_graph_max_band_words(b->n_planes);
     auto band_capacity = [](int W) { const int G = 64 * W; return 61 * (G + 1) - G - 64; };
     std::vector<launch_class> classes;
+    std::vector<uint32_t> sweep_pairs, sweep_flat;
+    std::vector<uint64_t> sweep_first, sweep_slot(N, 0);
+    int64_t sweep_dmax = 32768;                         // beyond: the table (D^2 / 2 words) and the single workgroup stop paying
+    if (const char *e = getenv("MALCS_SWEEP_DMAX")) sweep_dmax = atoll(e);
     for (uint64_t i = 0; i < N; i++) {
         const uint32_t m = b->a_len[i], n = b->b_len[i];
         pair_graph &G = out->g[i];
@@ -420,6 +427,11 @@ static int graph_batch(malcs_batch *b, const int64_t *shift, const int64_t *max_
         if (m == 0 || n == 0) continue;               // no DP needed: LLCS = 0
         int W = 0, logL = 0;
         bool band = false;
+        if (m >= 4096u && G.distance <= sweep_dmax) {  // long and similar: the output-sensitive sweeps (malcs_sweep.hip)
+            sweep_pairs.push_back((uint32_t)i);
+            has_runs[i] = 2;
+            continue;
+        }
         if (m < 4096u) {
             const uint32_t words = m / 64u + 1u;
             if (words <= 4) W = (int)pow2ceil(words);
@@ -453,6 +465,13 @@ static int graph_batch(malcs_batch *b, const int64_t *shift, const int64_t *max_
     const uint64_t budget_dwords = std::min<uint64_t>(free_b / 2, 64ull << 30) / 4;
 
     float ms_fwd = 0, ms_reach = 0;
+    if (!sweep_pairs.empty()) {
+        float ms[2] = {0, 0};
+        int rc = malcs_sweep_optimal_runs(b, sweep_pairs, dist.data(), sweep_flat, sweep_first, ms);
+        if (rc) return rc;
+        ms_fwd += ms[0]; ms_reach += ms[1];
+        for (size_t s = 0; s < sweep_pairs.size(); s++) sweep_slot[sweep_pairs[s]] = s;
+    }
     dev_buf<uint32_t> d_work, d_evcap, d_evcnt, d_scratch;
     dev_buf<uint64_t> d_scoff, d_evoff, d_outoff;
     dev_buf<int32_t> d_kmin, d_kmax, d_rw, d_llcs, d_fdist;
@@ -590,7 +609,12 @@ static int graph_batch(malcs_batch *b, const int64_t *shift, const int64_t *max_
             const int64_t m = b->a_len[i], n = b->b_len[i];
             runs.clear();
             const double ta = trace ? now_ms() : 0;
-            if (has_runs[i] && !runs_from_events(pair_events[i], m, n, runs)) { failed.store(1); continue; }
+            if (has_runs[i] == 2) {                                      // runs straight from the sweep kernels
+                const uint64_t s = sweep_slot[i];
+                for (uint64_t r = sweep_first[s]; r < sweep_first[s + 1]; r++)
+                    runs.push_back({sweep_flat[4 * r], sweep_flat[4 * r + 1], sweep_flat[4 * r + 2], sweep_flat[4 * r + 3]});
+                order_runs(runs, m, n);
+            } else if (has_runs[i] && !runs_from_events(pair_events[i], m, n, runs)) { failed.store(1); continue; }
             const double tb = trace ? now_ms() : 0;
             const int64_t llcs = (m + n - G.distance) / 2;
             G.n_levels = runs.empty() ? (std::min(m, n) > 0 ? 1 : 0) : llcs;

@@ -505,10 +505,19 @@ int malcs_dist_band(malcs_batch *b, const std::vector<uint32_t> &pairs, int32_t 
 {
     hipStream_t st = b->ctx->stream;
     const int wmax = max_words_per_lane(b->n_planes);
-    std::vector<uint32_t> todo(pairs);
-    std::vector<size_t> slot_of(pairs.size());
-    for (size_t i = 0; i < pairs.size(); i++) slot_of[i] = i;
+    std::vector<uint32_t> todo;
+    std::vector<size_t> slot_of;
     std::vector<int32_t> result(pairs.size(), -1);
+    {
+        // similar pairs first: the furthest-reaching sweep (malcs_sweep.hip) costs O(n / 32 + D^2), not columns x band
+        int32_t cap = 32768;
+        if (const char *e = getenv("MALCS_SWEEP_DCAP")) cap = atoi(e);
+        if (cap > 0) {
+            int rc0 = malcs_sweep_distances(b, pairs, cap, result);
+            if (rc0) return rc0;
+        }
+        for (size_t i = 0; i < pairs.size(); i++) if (result[i] < 0) { todo.push_back(pairs[i]); slot_of.push_back(i); }
+    }
     uint32_t *d_work = nullptr; int32_t *d_thresh = nullptr, *d_out = nullptr;
     MALCS_HIP(hipMalloc(&d_work, pairs.size() * 4)); MALCS_HIP(hipMalloc(&d_thresh, pairs.size() * 4)); MALCS_HIP(hipMalloc(&d_out, pairs.size() * 4));
     int rc = MALCS_OK;

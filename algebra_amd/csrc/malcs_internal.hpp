@@ -88,3 +88,6 @@ int malcs_diag_threshold(int nlw);
 int malcs_dist_plan(malcs_batch *b);
 int malcs_dist_launch(malcs_batch *b);
 int malcs_dist_band(malcs_batch *b, const std::vector<uint32_t> &pairs, int32_t *host_out);
+
+// malcs_sweep.hip
+int malcs_sweep_distances(malcs_batch *b, const std::vector<uint32_t> &pairs, int32_t cap, std::vector<int32_t> &out);

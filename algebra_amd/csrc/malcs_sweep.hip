@@ -121,10 +121,297 @@ k_lcs_sweep(const uint32_t *__restrict__ planes, const uint32_t *__restrict__ a_
     }
 }
 
+
+// ---- output-sensitive path for long, similar pairs ---------------------------------------------------------
+// The bit-vector kernels of malcs_graph.hip cost (columns x band) whatever the sequences hold; a pair of 1 Mb
+// windows a few dozen edits apart is one wave crawling along a million columns.  The furthest-reaching recurrence
+// costs O(n / 32 + D^2): slides compare 32 cells per step, and a slide that does not end within two words is
+// finished by the whole workgroup (every thread one word, first mismatch by an LDS minimum).
+//
+//   k_sweep_reach<NP, REV>   FR_d[k] for d = 0, 1, ... until the corner is reached (=> the distance, without
+//                            knowing it beforehand) or `cap` is exceeded.  REV walks the reversed sequences, i.e.
+//                            from the sink backwards, and with `tab` keeps every FR_d[k] (row d at d(d+1)/2,
+//                            entry (k + d) / 2): the backward reach table.
+//   k_sweep_runs<NP>         forward again, now knowing D and the table: on diagonal k at budget d the corners
+//                            (prev, FR_d[k]] all have forward cost d; such a corner lies on a minimal alignment
+//                            iff the sink reaches it with D - d, i.e. iff its row >= m - FRrev_{D-d}[delta - k].
+//                            Emits the maximal match runs that end in such a corner = exactly the runs the
+//                            reach kernel of malcs_graph.hip extracts (level = (row_end + col_end - d)/2 - 1).
+constexpr int SWEEP_THREADS = 512;
+constexpr int LOCAL_WORDS = 2;
+constexpr int SWEEP_UNROLL = 4;
+constexpr int32_t NO_STOP = 0x7fffffff;
+
+template <int NP>
+__device__ __forceinline__ uint32_t bits_at(const uint32_t *__restrict__ S, uint32_t nblk, int32_t start, int p)
+{
+    const int32_t j = start >> 5;                                             // floor, also for negative starts
+    const uint32_t s = (uint32_t)start & 31u;
+    // unconditional loads from clamped blocks (nblk >= 1), so that the loads of several diagonals can be in flight
+    const int32_t last = (int32_t)nblk - 1;
+    const uint32_t l0 = S[(uint32_t)min(max(j, 0), last) * NP + p], l1 = S[(uint32_t)min(max(j + 1, 0), last) * NP + p];
+    const uint32_t lo = (j >= 0 && j <= last) ? l0 : 0u;
+    const uint32_t hi = (j + 1 >= 0 && j + 1 <= last) ? l1 : 0u;
+    return (uint32_t)((((uint64_t)hi << 32) | lo) >> s);
+}
+
+// mismatch bits of the 32 cells (row + i, col + i); REV: of the problem on the reversed sequences, where cell
+// (r, c) is the original cell (m - 1 - r, n - 1 - c).  Cells outside the matrix come out arbitrary.
+template <int NP, bool REV>
+__device__ __forceinline__ uint32_t cells32(const uint32_t *__restrict__ A, uint32_t na, int32_t m,
+                                            const uint32_t *__restrict__ B, uint32_t nb, int32_t n, int32_t row, int32_t col)
+{
+    uint32_t mism = 0;
+    const int32_t sa = REV ? m - 32 - row : row, sb = REV ? n - 32 - col : col;
+#pragma unroll
+    for (int p = 0; p < NP; p++) mism |= bits_at<NP>(A, na, sa, p) ^ bits_at<NP>(B, nb, sb, p);
+    return REV ? __brev(mism) : mism;
+}
+
+struct sweep_queue {
+    int32_t n;
+    int32_t pos[SWEEP_THREADS * SWEEP_UNROLL], k[SWEEP_THREADS * SWEEP_UNROLL], stop[SWEEP_THREADS * SWEEP_UNROLL];
+    int32_t first[3];
+};
+
+// the slides the lanes could not finish, one after the other, all threads on each
+template <int NP, bool REV>
+__device__ __forceinline__ void finish_slides(sweep_queue &q, const uint32_t *A, uint32_t na, int32_t m, const uint32_t *B,
+                                              uint32_t nb, int32_t n)
+{
+    const int32_t nq = q.n;
+    for (int32_t i = 0; i < nq; i++) {
+        const int32_t k = q.k[i], limit = min(m, n - k);
+        int32_t pos = q.pos[i];
+        if (threadIdx.x == 0) q.first[0] = NO_STOP;
+        __syncthreads();
+        // round r collects in slot r % 3 while thread 0 clears slot (r + 1) % 3; slot (r + 2) % 3 may still be read
+        for (uint32_t round = 0;; round++) {
+            if (threadIdx.x == 0) q.first[(round + 1u) % 3u] = NO_STOP;
+            const int32_t p = pos + 32 * (int32_t)threadIdx.x;
+            if (p < limit) {
+                uint32_t mism = cells32<NP, REV>(A, na, m, B, nb, n, p, p + k);
+                const int32_t valid = limit - p;
+                if (valid < 32) mism |= ~0u << valid;
+                if (mism) atomicMin(&q.first[round % 3u], p + (int32_t)__builtin_ctz(mism));
+            } else if (p - 32 < limit) {
+                atomicMin(&q.first[round % 3u], limit);                       // the slide ran into the edge of the matrix
+            }
+            __syncthreads();
+            const int32_t f = q.first[round % 3u];
+            if (f != NO_STOP) { if (threadIdx.x == 0) q.stop[i] = f; break; }
+            pos += 32 * SWEEP_THREADS;
+        }
+        __syncthreads();                                                      // everyone has read the slot before it is reused
+    }
+}
+
+template <int NP, bool REV>
+__global__ void __launch_bounds__(SWEEP_THREADS)
+k_sweep_reach(const uint32_t *__restrict__ planes, const uint32_t *__restrict__ a_off, const uint32_t *__restrict__ a_len,
+              const uint32_t *__restrict__ b_off, const uint32_t *__restrict__ b_len, const uint32_t *__restrict__ work,
+              const int32_t *__restrict__ caps, int32_t *__restrict__ fr_scratch, const uint64_t *__restrict__ fr_off,
+              int32_t *__restrict__ tab, const uint64_t *__restrict__ tab_off, int32_t *__restrict__ dist_out)
+{
+    __shared__ int32_t lds_fr[LDS_DIAGS];
+    __shared__ sweep_queue q;
+    const uint32_t w = blockIdx.x, pid = work[w];
+    const int32_t m = (int32_t)a_len[pid], n = (int32_t)b_len[pid], delta = n - m, cap = caps[w];
+    const uint32_t *A = planes + a_off[pid], *B = planes + b_off[pid];
+    const uint32_t na = ((uint32_t)m + 31u) >> 5, nb = ((uint32_t)n + 31u) >> 5;
+    const int32_t ndiag = 2 * cap + 3;                                        // k in [-cap - 1, cap + 1]
+    int32_t *FR = ndiag <= LDS_DIAGS ? lds_fr : fr_scratch + fr_off[w];
+    int32_t *T = tab ? tab + tab_off[w] : nullptr;
+    for (int32_t i = (int32_t)threadIdx.x; i < ndiag; i += SWEEP_THREADS) {
+        const int32_t k = i - cap - 1;
+        FR[i] = (k < 0 ? -k : 0) - 1;
+    }
+    if (threadIdx.x == 0) { q.n = 0; q.first[0] = NO_STOP; }
+    __syncthreads();
+    int32_t found = -1;
+    const bool corner_on_band = delta >= -cap && delta <= cap;
+    for (int32_t d = 0; d <= cap && corner_on_band; d++) {
+        int32_t klo = max(-d, -m), khi = min(d, n);
+        if ((klo + d) & 1) klo++;
+        if ((khi + d) & 1) khi--;
+        const int32_t nk = khi >= klo ? (khi - klo) / 2 + 1 : 0;
+        // a thread takes SWEEP_UNROLL diagonals of a chunk: their loads are independent and overlap
+        for (int32_t base = 0; base < nk; base += SWEEP_THREADS * SWEEP_UNROLL) {
+            int32_t stop[SWEEP_UNROLL], pos[SWEEP_UNROLL], slot[SWEEP_UNROLL];
+            uint32_t mism[SWEEP_UNROLL];
+            bool mine[SWEEP_UNROLL], open[SWEEP_UNROLL];
+#pragma unroll
+            for (int u = 0; u < SWEEP_UNROLL; u++) {
+                const int32_t i = base + u * SWEEP_THREADS + (int32_t)threadIdx.x;
+                mine[u] = i < nk;
+                const int32_t k = klo + 2 * (mine[u] ? i : 0), idx = k + cap + 1;
+                const int32_t prev = FR[idx], limit = min(m, n - k);
+                stop[u] = prev;
+                slot[u] = -1;
+                open[u] = mine[u] && prev < limit;
+                pos[u] = min(max(max(FR[idx - 1], FR[idx + 1] + 1), prev + 1), limit);
+            }
+#pragma unroll
+            for (int u = 0; u < SWEEP_UNROLL; u++) {
+                const int32_t i = base + u * SWEEP_THREADS + (int32_t)threadIdx.x;
+                const int32_t k = klo + 2 * (mine[u] ? i : 0);
+                mism[u] = cells32<NP, REV>(A, na, m, B, nb, n, pos[u], pos[u] + k);
+            }
+            bool queued = false;
+#pragma unroll
+            for (int u = 0; u < SWEEP_UNROLL; u++) {
+                if (!open[u]) continue;
+                const int32_t i = base + u * SWEEP_THREADS + (int32_t)threadIdx.x;
+                const int32_t k = klo + 2 * i, limit = min(m, n - k);
+                uint32_t mm = mism[u];
+                int32_t p = pos[u], st = NO_STOP;
+                for (int wi = 0;; wi++) {
+                    const int32_t valid = limit - p;
+                    if (valid < 32) mm |= valid <= 0 ? ~0u : (~0u << valid);
+                    if (mm) { st = p + (int32_t)__builtin_ctz(mm); break; }
+                    p += 32;
+                    if (wi + 1 == LOCAL_WORDS) break;
+                    mm = cells32<NP, REV>(A, na, m, B, nb, n, p, p + k);
+                }
+                stop[u] = st;
+                if (st == NO_STOP) { slot[u] = atomicAdd(&q.n, 1); q.pos[slot[u]] = p; q.k[slot[u]] = k; queued = true; }
+            }
+            if (__syncthreads_or(queued)) {                                   // rare: somebody's slide goes on
+                finish_slides<NP, REV>(q, A, na, m, B, nb, n);
+                if (threadIdx.x == 0) q.n = 0;                                // everybody has read it (barriers inside)
+                __syncthreads();
+#pragma unroll
+                for (int u = 0; u < SWEEP_UNROLL; u++) if (slot[u] >= 0) stop[u] = q.stop[slot[u]];
+            }
+#pragma unroll
+            for (int u = 0; u < SWEEP_UNROLL; u++) {
+                if (!mine[u]) continue;
+                const int32_t i = base + u * SWEEP_THREADS + (int32_t)threadIdx.x;
+                const int32_t k = klo + 2 * i;
+                FR[k + cap + 1] = stop[u];                                    // own parity: nobody else reads it in this step
+                if (T) T[(int64_t)d * (d + 1) / 2 + (k + d) / 2] = stop[u];
+            }
+        }
+        __syncthreads();                                                      // budget d + 1 reads what budget d wrote
+        if (FR[delta + cap + 1] >= m) { found = d; break; }                   // the same LDS / HBM word for every thread
+    }
+    if (threadIdx.x == 0) dist_out[w] = found;
+}
+
+template <int NP>
+__global__ void __launch_bounds__(SWEEP_THREADS)
+k_sweep_runs(const uint32_t *__restrict__ planes, const uint32_t *__restrict__ a_off, const uint32_t *__restrict__ a_len,
+             const uint32_t *__restrict__ b_off, const uint32_t *__restrict__ b_len, const uint32_t *__restrict__ work,
+             const int32_t *__restrict__ dists, int32_t *__restrict__ fr_scratch, const uint64_t *__restrict__ fr_off,
+             const int32_t *__restrict__ tab, const uint64_t *__restrict__ tab_off,
+             uint4 *__restrict__ out, const uint64_t *__restrict__ out_off, const uint32_t *__restrict__ out_cap,
+             uint32_t *__restrict__ out_cnt)
+{
+    __shared__ int32_t lds_fr[LDS_DIAGS];
+    __shared__ sweep_queue q;
+    __shared__ uint32_t lds_cnt;
+    const uint32_t w = blockIdx.x, pid = work[w];
+    const int32_t m = (int32_t)a_len[pid], n = (int32_t)b_len[pid], delta = n - m, D = dists[w];
+    const uint32_t *A = planes + a_off[pid], *B = planes + b_off[pid];
+    const uint32_t na = ((uint32_t)m + 31u) >> 5, nb = ((uint32_t)n + 31u) >> 5;
+    const int32_t kmin = -((D - delta) / 2), kmax = (D + delta) / 2, ndiag = kmax - kmin + 3;
+    int32_t *FR = ndiag <= LDS_DIAGS ? lds_fr : fr_scratch + fr_off[w];
+    const int32_t *T = tab + tab_off[w];
+    uint4 *dst = out + out_off[w];
+    const uint32_t cap = out_cap[w];
+    for (int32_t i = (int32_t)threadIdx.x; i < ndiag; i += SWEEP_THREADS) {
+        const int32_t k = kmin - 1 + i;
+        FR[i] = (k < 0 ? -k : 0) - 1;
+    }
+    if (threadIdx.x == 0) { q.n = 0; q.first[0] = NO_STOP; lds_cnt = 0; }
+    __syncthreads();
+    auto emit = [&](int32_t start, int32_t end, int32_t k, int32_t d) {
+        const uint32_t slot = atomicAdd(&lds_cnt, 1u);
+        if (slot < cap) dst[slot] = make_uint4((uint32_t)start, (uint32_t)(start + k), (uint32_t)(end - start), (uint32_t)((2 * end + k - d) / 2 - 1));
+    };
+    for (int32_t d = 0; d <= D; d++) {
+        const int32_t klo = max(-d, delta - (D - d)), khi = min(d, delta + (D - d));
+        const int32_t nk = khi >= klo ? (khi - klo) / 2 + 1 : 0;
+        for (int32_t base = 0; base < nk; base += SWEEP_THREADS) {
+            const int32_t i = base + (int32_t)threadIdx.x;
+            const bool mine = i < nk;
+            const int32_t k = klo + 2 * i, idx = k - kmin + 1;
+            int32_t stop = 0, slot = -1, prev = 0, x = 0;
+            bool active = false;
+            if (mine) {
+                prev = FR[idx];
+                const int32_t limit = min(m, n - k);
+                stop = prev;
+                if (prev < limit) {
+                    active = true;
+                    x = min(max(max(FR[idx - 1], FR[idx + 1] + 1), prev + 1), limit);
+                    int32_t pos = x;
+                    stop = NO_STOP;
+#pragma unroll 1
+                    for (int wi = 0; wi < LOCAL_WORDS && stop == NO_STOP; wi++) {
+                        uint32_t mism = cells32<NP, false>(A, na, m, B, nb, n, pos, pos + k);
+                        const int32_t valid = limit - pos;
+                        if (valid < 32) mism |= valid <= 0 ? ~0u : (~0u << valid);
+                        if (mism) stop = pos + (int32_t)__builtin_ctz(mism); else pos += 32;
+                    }
+                    if (stop == NO_STOP) { slot = atomicAdd(&q.n, 1); q.pos[slot] = pos; q.k[slot] = k; }
+                }
+            }
+            if (__syncthreads_or(slot >= 0)) {                                // rare: somebody's slide goes on
+                finish_slides<NP, false>(q, A, na, m, B, nb, n);
+                if (threadIdx.x == 0) q.n = 0;                                // everybody has read it (barriers inside)
+                __syncthreads();
+                if (slot >= 0) stop = q.stop[slot];
+            }
+            if (mine) FR[idx] = stop;                                         // own parity: nobody else reads it in this step
+            if (active) {
+                const int32_t dd = D - d, kk = delta - k;
+                const int32_t lo = max(prev + 1, m - T[(int64_t)dd * (dd + 1) / 2 + (kk + dd) / 2]);   // first corner the sink reaches
+                if (stop >= lo) {
+                    // start of the run that holds cell s0 - 1 (cells before prev + 1 belong to an earlier budget)
+                    const int32_t s0 = min(lo, x);
+                    int32_t s = s0;
+                    while (s > prev + 1) {
+                        const int32_t ws = s - 32;
+                        uint32_t mism = cells32<NP, false>(A, na, m, B, nb, n, ws, ws + k);
+                        const int32_t before = prev + 1 - ws;
+                        if (before > 0) mism |= before >= 32 ? ~0u : ((1u << before) - 1u);
+                        if (mism) { s = ws + 32 - (int32_t)__builtin_clz(mism); break; }
+                        s = ws;
+                    }
+                    // the cells before x: runs may end there
+                    int32_t pos = s, run_start = s;
+                    uint32_t in_run = 0;
+                    while (pos < x) {
+                        const uint32_t mism = cells32<NP, false>(A, na, m, B, nb, n, pos, pos + k);
+                        const int32_t nbits = min(32, x - pos);
+                        const uint32_t low = nbits == 32 ? ~0u : ((1u << nbits) - 1u);
+                        const uint32_t match = ~mism & low;
+                        uint32_t turn = (match ^ ((match << 1) | in_run)) & low;
+                        while (turn) {
+                            const int32_t t = __builtin_ctz(turn);
+                            turn &= turn - 1u;
+                            if ((match >> t) & 1u) run_start = pos + t;
+                            else if (pos + t >= lo) emit(run_start, pos + t, k, d);
+                        }
+                        in_run = (match >> (nbits - 1)) & 1u;
+                        pos += 32;
+                    }
+                    // from x on everything up to `stop` matches
+                    const int32_t fs = in_run ? run_start : x;
+                    if (stop > fs) emit(fs, stop, k, d);
+                }
+            }
+        }
+        __syncthreads();                                                      // budget d + 1 reads what budget d wrote
+    }
+    if (threadIdx.x == 0) out_cnt[w] = lds_cnt;
+}
+
 template <typename T> struct dbuf {
     T *p = nullptr;
     ~dbuf() { if (p) hipFree(p); }
-    int alloc(size_t n) { return hipMalloc(&p, (n ? n : 1) * sizeof(T)) == hipSuccess ? 0 : -1; }
+    int alloc(size_t n) { return hipMalloc(&p, (n ? n : 1) * sizeof(T)) == hipSuccess ? 0 : -1; }   // once per buffer
 };
 
 template <int NP>
@@ -225,6 +512,200 @@ int malcs_sweep_runs(malcs_batch *b, const std::vector<uint32_t> &work, const in
         if (total) MALCS_HIP(hipMemcpyAsync(out_runs.data() + base, d_out.p, total * 16ull, hipMemcpyDeviceToHost, st));
         MALCS_HIP(hipStreamSynchronize(st));
         for (uint32_t s = 0; s < cnt; s++) out_first[pos + s + 1] = base / 4 + off[s] + counts[s];
+        pos = end;
+    }
+    return MALCS_OK;
+}
+
+namespace {
+
+template <int NP>
+int launch_reach(malcs_batch *b, bool rev, uint32_t count, const uint32_t *d_work, const int32_t *d_caps, int32_t *d_fr,
+                 const uint64_t *d_fr_off, int32_t *d_tab, const uint64_t *d_tab_off, int32_t *d_dist)
+{
+    if (rev) hipLaunchKernelGGL((k_sweep_reach<NP, true>), dim3(count), dim3(SWEEP_THREADS), 0, b->ctx->stream, b->d_planes, b->d_a_off,
+                                b->d_a_len, b->d_b_off, b->d_b_len, d_work, d_caps, d_fr, d_fr_off, d_tab, d_tab_off, d_dist);
+    else hipLaunchKernelGGL((k_sweep_reach<NP, false>), dim3(count), dim3(SWEEP_THREADS), 0, b->ctx->stream, b->d_planes, b->d_a_off,
+                            b->d_a_len, b->d_b_off, b->d_b_len, d_work, d_caps, d_fr, d_fr_off, d_tab, d_tab_off, d_dist);
+    MALCS_HIP(hipGetLastError());
+    return MALCS_OK;
+}
+
+int launch_reach_any(malcs_batch *b, bool rev, uint32_t count, const uint32_t *d_work, const int32_t *d_caps, int32_t *d_fr,
+                     const uint64_t *d_fr_off, int32_t *d_tab, const uint64_t *d_tab_off, int32_t *d_dist)
+{
+    switch (b->n_planes) {
+    case 2: return launch_reach<2>(b, rev, count, d_work, d_caps, d_fr, d_fr_off, d_tab, d_tab_off, d_dist);
+    case 3: return launch_reach<3>(b, rev, count, d_work, d_caps, d_fr, d_fr_off, d_tab, d_tab_off, d_dist);
+    case 4: return launch_reach<4>(b, rev, count, d_work, d_caps, d_fr, d_fr_off, d_tab, d_tab_off, d_dist);
+    case 8: return launch_reach<8>(b, rev, count, d_work, d_caps, d_fr, d_fr_off, d_tab, d_tab_off, d_dist);
+    }
+    malcs_set_error("unsupported plane count %d", b->n_planes);
+    return MALCS_ERR_ARG;
+}
+
+template <int NP>
+int launch_runs(malcs_batch *b, uint32_t count, const uint32_t *d_work, const int32_t *d_dists, int32_t *d_fr, const uint64_t *d_fr_off,
+                const int32_t *d_tab, const uint64_t *d_tab_off, uint4 *d_out, const uint64_t *d_out_off, const uint32_t *d_out_cap,
+                uint32_t *d_out_cnt)
+{
+    hipLaunchKernelGGL((k_sweep_runs<NP>), dim3(count), dim3(SWEEP_THREADS), 0, b->ctx->stream, b->d_planes, b->d_a_off, b->d_a_len,
+                       b->d_b_off, b->d_b_len, d_work, d_dists, d_fr, d_fr_off, d_tab, d_tab_off, d_out, d_out_off, d_out_cap, d_out_cnt);
+    MALCS_HIP(hipGetLastError());
+    return MALCS_OK;
+}
+
+// scratch for FR: pairs whose diagonals do not fit LDS
+uint64_t fr_layout(const std::vector<int64_t> &ndiag, std::vector<uint64_t> &off)
+{
+    uint64_t total = 0;
+    off.resize(ndiag.size());
+    for (size_t i = 0; i < ndiag.size(); i++) { off[i] = total; if (ndiag[i] > LDS_DIAGS) total += (uint64_t)ndiag[i]; }
+    return total;
+}
+
+}  // namespace
+
+// Distances of long pairs without a bound known beforehand: forward sweep until the corner, at most `cap` edits.
+// out[i] = distance of pairs[i], or -1 when it exceeds cap.  Synchronous.
+int malcs_sweep_distances(malcs_batch *b, const std::vector<uint32_t> &pairs, int32_t cap, std::vector<int32_t> &out)
+{
+    hipStream_t st = b->ctx->stream;
+    const uint32_t cnt = (uint32_t)pairs.size();
+    out.assign(cnt, -1);
+    if (!cnt) return MALCS_OK;
+    std::vector<int32_t> caps(cnt);
+    std::vector<int64_t> ndiag(cnt);
+    for (uint32_t i = 0; i < cnt; i++) {
+        caps[i] = (int32_t)std::min<int64_t>(cap, (int64_t)b->a_len[pairs[i]] + b->b_len[pairs[i]]);
+        ndiag[i] = 2 * (int64_t)caps[i] + 3;
+    }
+    std::vector<uint64_t> fr_off;
+    const uint64_t fr_total = fr_layout(ndiag, fr_off);
+    dbuf<uint32_t> d_work;
+    dbuf<int32_t> d_caps, d_fr, d_dist;
+    dbuf<uint64_t> d_fr_off;
+    if (d_work.alloc(cnt) || d_caps.alloc(cnt) || d_fr.alloc(fr_total) || d_dist.alloc(cnt) || d_fr_off.alloc(cnt)) {
+        malcs_set_error("device allocation failed (sweep over %u pairs)", cnt);
+        return MALCS_ERR_NOMEM;
+    }
+    MALCS_HIP(hipMemcpyAsync(d_work.p, pairs.data(), cnt * 4ull, hipMemcpyHostToDevice, st));
+    MALCS_HIP(hipMemcpyAsync(d_caps.p, caps.data(), cnt * 4ull, hipMemcpyHostToDevice, st));
+    MALCS_HIP(hipMemcpyAsync(d_fr_off.p, fr_off.data(), cnt * 8ull, hipMemcpyHostToDevice, st));
+    int rc = launch_reach_any(b, false, cnt, d_work.p, d_caps.p, d_fr.p, d_fr_off.p, nullptr, nullptr, d_dist.p);
+    if (rc) return rc;
+    MALCS_HIP(hipMemcpyAsync(out.data(), d_dist.p, cnt * 4ull, hipMemcpyDeviceToHost, st));
+    MALCS_HIP(hipStreamSynchronize(st));
+    return MALCS_OK;
+}
+
+// Runs on the minimal alignments of the pairs in `work` (distances known: dist[pid]) by the two sweeps: backward
+// with the reach table, forward with emission.  Output as malcs_sweep_runs.  ms[0] += backward, ms[1] += forward pass.
+int malcs_sweep_optimal_runs(malcs_batch *b, const std::vector<uint32_t> &work, const int32_t *dist,
+                             std::vector<uint32_t> &out_runs, std::vector<uint64_t> &out_first, float *ms)
+{
+    hipStream_t st = b->ctx->stream;
+    malcs_ctx *ctx = b->ctx;
+    out_first.assign(work.size() + 1, 0);
+    out_runs.clear();
+    size_t free_b = 0, total_b = 0;
+    MALCS_HIP(hipMemGetInfo(&free_b, &total_b));
+    const uint64_t budget = std::min<uint64_t>(free_b / 2, 64ull << 30) / 4;  // ints of table per chunk
+    size_t pos = 0;
+    while (pos < work.size()) {
+        std::vector<uint64_t> tab_off;
+        std::vector<int32_t> dists;
+        std::vector<int64_t> nd_back, nd_fwd;
+        uint64_t tab_total = 0;
+        size_t end = pos;
+        while (end < work.size()) {
+            const int64_t D = dist[work[end]];
+            const uint64_t need = (uint64_t)(D + 1) * (uint64_t)(D + 2) / 2;
+            if (end > pos && tab_total + need > budget) break;
+            if (need > budget) {
+                malcs_set_error("pair %u at distance %lld needs %llu MiB of reach table; the device has %llu MiB free", work[end],
+                                (long long)D, (unsigned long long)(need >> 18), (unsigned long long)(free_b >> 20));
+                return MALCS_ERR_NOMEM;
+            }
+            tab_off.push_back(tab_total); tab_total += need; dists.push_back((int32_t)D);
+            nd_back.push_back(2 * D + 3); nd_fwd.push_back(D + 3);
+            end++;
+        }
+        const uint32_t cnt = (uint32_t)(end - pos);
+        std::vector<uint64_t> fr_off_b, fr_off_f;
+        const uint64_t fr_b = fr_layout(nd_back, fr_off_b), fr_f = fr_layout(nd_fwd, fr_off_f);
+        dbuf<uint32_t> d_work, d_cap, d_cnt;
+        dbuf<int32_t> d_dists, d_fr, d_tab, d_found;
+        dbuf<uint64_t> d_fr_off, d_tab_off, d_out_off;
+        dbuf<uint4> d_out;
+        if (d_work.alloc(cnt) || d_cap.alloc(cnt) || d_cnt.alloc(cnt) || d_dists.alloc(cnt) || d_fr.alloc(std::max(fr_b, fr_f)) ||
+            d_tab.alloc(tab_total) || d_found.alloc(cnt) || d_fr_off.alloc(cnt) || d_tab_off.alloc(cnt) || d_out_off.alloc(cnt)) {
+            malcs_set_error("device allocation failed (sweep chunk of %u pairs, %llu MiB of reach table)", cnt, (unsigned long long)(tab_total >> 18));
+            return MALCS_ERR_NOMEM;
+        }
+        MALCS_HIP(hipMemcpyAsync(d_work.p, work.data() + pos, cnt * 4ull, hipMemcpyHostToDevice, st));
+        MALCS_HIP(hipMemcpyAsync(d_dists.p, dists.data(), cnt * 4ull, hipMemcpyHostToDevice, st));
+        MALCS_HIP(hipMemcpyAsync(d_tab_off.p, tab_off.data(), cnt * 8ull, hipMemcpyHostToDevice, st));
+        MALCS_HIP(hipMemcpyAsync(d_fr_off.p, fr_off_b.data(), cnt * 8ull, hipMemcpyHostToDevice, st));
+        MALCS_HIP(hipMemsetAsync(d_tab.p, 0xff, tab_total * 4ull, st));       // an entry never written reaches nothing
+        MALCS_HIP(hipEventRecord(ctx->ev0, st));
+        int rc = launch_reach_any(b, true, cnt, d_work.p, d_dists.p, d_fr.p, d_fr_off.p, d_tab.p, d_tab_off.p, d_found.p);
+        if (rc) return rc;
+        MALCS_HIP(hipEventRecord(ctx->ev1, st));
+        std::vector<int32_t> found(cnt);
+        MALCS_HIP(hipMemcpyAsync(found.data(), d_found.p, cnt * 4ull, hipMemcpyDeviceToHost, st));
+        MALCS_HIP(hipStreamSynchronize(st));
+        float t = 0;
+        MALCS_HIP(hipEventElapsedTime(&t, ctx->ev0, ctx->ev1));
+        ms[0] += t;
+        std::vector<uint32_t> cap(cnt), got(cnt);
+        std::vector<uint64_t> off(cnt);
+        uint64_t total = 0;
+        for (uint32_t s = 0; s < cnt; s++) {
+            if (found[s] != dists[s]) {
+                malcs_set_error("pair %u: the backward sweep found distance %d, expected %d (internal error)", work[pos + s], found[s], dists[s]);
+                return MALCS_ERR_INTERNAL;
+            }
+            cap[s] = 64u + 16u * (uint32_t)dists[s];
+            off[s] = total; total += cap[s];
+        }
+        MALCS_HIP(hipMemcpyAsync(d_fr_off.p, fr_off_f.data(), cnt * 8ull, hipMemcpyHostToDevice, st));
+        for (int attempt = 0;; attempt++) {
+            if (d_out.p) { hipFree(d_out.p); d_out.p = nullptr; }
+            if (d_out.alloc(total)) { malcs_set_error("device allocation failed (%llu runs)", (unsigned long long)total); return MALCS_ERR_NOMEM; }
+            MALCS_HIP(hipMemcpyAsync(d_cap.p, cap.data(), cnt * 4ull, hipMemcpyHostToDevice, st));
+            MALCS_HIP(hipMemcpyAsync(d_out_off.p, off.data(), cnt * 8ull, hipMemcpyHostToDevice, st));
+            MALCS_HIP(hipEventRecord(ctx->ev1, st));
+            switch (b->n_planes) {
+            case 2: rc = launch_runs<2>(b, cnt, d_work.p, d_dists.p, d_fr.p, d_fr_off.p, d_tab.p, d_tab_off.p, d_out.p, d_out_off.p, d_cap.p, d_cnt.p); break;
+            case 3: rc = launch_runs<3>(b, cnt, d_work.p, d_dists.p, d_fr.p, d_fr_off.p, d_tab.p, d_tab_off.p, d_out.p, d_out_off.p, d_cap.p, d_cnt.p); break;
+            case 4: rc = launch_runs<4>(b, cnt, d_work.p, d_dists.p, d_fr.p, d_fr_off.p, d_tab.p, d_tab_off.p, d_out.p, d_out_off.p, d_cap.p, d_cnt.p); break;
+            case 8: rc = launch_runs<8>(b, cnt, d_work.p, d_dists.p, d_fr.p, d_fr_off.p, d_tab.p, d_tab_off.p, d_out.p, d_out_off.p, d_cap.p, d_cnt.p); break;
+            default: malcs_set_error("unsupported plane count %d", b->n_planes); rc = MALCS_ERR_ARG;
+            }
+            if (rc) return rc;
+            MALCS_HIP(hipEventRecord(ctx->ev2, st));
+            MALCS_HIP(hipMemcpyAsync(got.data(), d_cnt.p, cnt * 4ull, hipMemcpyDeviceToHost, st));
+            MALCS_HIP(hipStreamSynchronize(st));
+            MALCS_HIP(hipEventElapsedTime(&t, ctx->ev1, ctx->ev2));
+            ms[1] += t;
+            bool overflow = false;
+            for (uint32_t s = 0; s < cnt; s++) if (got[s] > cap[s]) overflow = true;
+            if (!overflow) break;
+            if (attempt) { malcs_set_error("run buffer overflow persisted after a resize"); return MALCS_ERR_INTERNAL; }
+            total = 0;                                                        // the counts are exact: size every region to its count, redo
+            for (uint32_t s = 0; s < cnt; s++) { cap[s] = std::max(cap[s], got[s]); off[s] = total; total += cap[s]; }
+        }
+        size_t base = out_runs.size();
+        uint64_t kept = 0;
+        for (uint32_t s = 0; s < cnt; s++) kept += got[s];
+        out_runs.resize(base + kept * 4);                                     // once, before any copy lands in it
+        for (uint32_t s = 0; s < cnt; s++) {
+            if (got[s]) MALCS_HIP(hipMemcpyAsync(out_runs.data() + base, d_out.p + off[s], (size_t)got[s] * 16ull, hipMemcpyDeviceToHost, st));
+            base += (size_t)got[s] * 4;
+            out_first[pos + s + 1] = base >> 2;
+        }
+        MALCS_HIP(hipStreamSynchronize(st));
         pos = end;
     }
     return MALCS_OK;

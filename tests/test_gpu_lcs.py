@@ -77,9 +77,19 @@ def test_edit_distance_long_patterns(native):
     assert got.tolist() == [O.edit_distance(a, b) for a, b in pairs]
 
 
-def test_edit_distance_sliding_window(native):
-    """Sequences longer than a resident pattern (> 65 536): sliding-window kernel, incl. the 100 kb and
-    1 Mb pairs whose distances were captured from the reference."""
+def use_path(monkeypatch, path):
+    """Long pairs have two device paths with identical results: the output-sensitive sweeps (default for similar
+    pairs) and the bit-vector band kernels (what remains for divergent ones); "band" switches the sweeps off."""
+    if path == "band":
+        monkeypatch.setenv("MALCS_SWEEP_DMAX", "-1")
+        monkeypatch.setenv("MALCS_SWEEP_DCAP", "0")
+
+
+@pytest.mark.parametrize("path", ["sweep", "band"])
+def test_edit_distance_sliding_window(native, path, monkeypatch):
+    """Sequences longer than a resident pattern (> 65 536): furthest-reaching sweep / sliding-window kernel,
+    incl. the 100 kb and 1 Mb pairs whose distances were captured from the reference."""
+    use_path(monkeypatch, path)
     from oracle import oracle as O
     import algebra_amd
     pairs, want = [], []
@@ -401,11 +411,13 @@ def test_from_variant_and_from_supremal(native):
         assert graph_record(graph) == rec["graph"]
 
 
+@pytest.mark.parametrize("path", ["sweep", "band"])
 @pytest.mark.parametrize("idx", range(len(LARGE["from_sequence"])))
-def test_large_from_sequence(native, idx):
+def test_large_from_sequence(native, idx, path, monkeypatch):
     """BASELINE configs 3 and 5 (i): 10 kb tandem-repeat windows, 100 kb and 1 Mb sparse pairs; full graph,
     SHA-256 of the canonical record captured from the reference."""
     from algebra_amd.lcs import LCSgraph
+    use_path(monkeypatch, path)
     rec = LARGE["from_sequence"][idx]
     a, b = gen.large_pair(rec["case"])
     assert digest([a, b]) == rec["input_sha256"]
@@ -425,10 +437,13 @@ def test_graph_size_limit_is_loud(native):
         LCSgraph(a, b)
 
 
-def test_graph_band_vs_oracle(native):
-    """Windows beyond 4 095 symbols run the sliding-window kernels: all band widths, both signs of n - m."""
+@pytest.mark.parametrize("path", ["sweep", "band"])
+def test_graph_band_vs_oracle(native, path, monkeypatch):
+    """Windows beyond 4 095 symbols: the two sweeps, or the sliding-window kernels at all band widths; both signs
+    of n - m."""
     from oracle import oracle as O
     from algebra_amd.lcs.encoding import encode_pairs
+    use_path(monkeypatch, path)
     rs = np.random.RandomState(21)
     pairs = []
     for m, p in ((4096, 0.002), (5000, 0.01), (8000, 0.05), (12000, 0.1), (9000, 0.3), (20000, 0.004)):
