@@ -164,6 +164,19 @@ void build_graph(int64_t m, int64_t n, int64_t shift, const std::vector<run> &ru
 
         int64_t max_sink = 0;
         for (int64_t depth = n_levels + 1; depth > 1; depth--) {         // depth == len_lcs_nodes, :389
+            // Levels without runs of their own under a single live node only shorten that node by one each (no parent
+            // to meet, :418-423), under no node at all they do nothing: take them in one stride.  A 1 Mb window a
+            // few edits from its reference is almost nothing but such levels.
+            const int64_t idle = depth - 2 - (unread ? runs[unread - 1].level : -1);   // levels until the next run
+            if (idle > 0 && cur.size() <= 1) {
+                int64_t stride = idle;
+                if (cur.size() == 1) {
+                    const int32_t node = cur[0];
+                    if (node != sink && B.out[node].empty()) { cur.clear(); }
+                    else { stride = std::min<int64_t>(idle, B.wlen[node] - 1); B.wlen[node] -= stride; }
+                }
+                if (stride > 0) { depth -= stride - 1; continue; }
+            }
             size_t first = unread;
             while (first > 0 && runs[first - 1].level == depth - 2) first--;
             below.clear();
