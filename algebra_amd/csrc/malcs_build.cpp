@@ -644,7 +644,13 @@ static int graph_batch(malcs_batch *b, const int64_t *shift, const int64_t *max_
         }
     };
     unsigned nt = std::min<unsigned>(16u, std::max(1u, std::thread::hardware_concurrency()));
-    if (N < 64) nt = 1;
+    {
+        // threads pay from a few thousand runs on (a 10 kb tandem-repeat window alone builds 400 000 edges)
+        uint64_t load = sweep_flat.size() / 4;
+        for (uint64_t i = 0; i < N; i++) load += pair_events[i].n / 2;
+        if (N < 64 && load < 4096) nt = 1;
+        nt = (unsigned)std::min<uint64_t>(nt, std::max<uint64_t>(N, 1));
+    }
     std::vector<std::thread> pool;
     for (unsigned t = 1; t < nt; t++) pool.emplace_back(worker);
     worker();

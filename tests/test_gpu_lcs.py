@@ -83,9 +83,12 @@ def use_path(monkeypatch, path):
     if path == "band":
         monkeypatch.setenv("MALCS_SWEEP_DMAX", "-1")
         monkeypatch.setenv("MALCS_SWEEP_DCAP", "0")
+    elif path == "mixed":                      # sweeps give up early: their results and the band kernels' in one batch
+        monkeypatch.setenv("MALCS_SWEEP_DMAX", "700")
+        monkeypatch.setenv("MALCS_SWEEP_DCAP", "700")
 
 
-@pytest.mark.parametrize("path", ["sweep", "band"])
+@pytest.mark.parametrize("path", ["sweep", "band", "mixed"])
 def test_edit_distance_sliding_window(native, path, monkeypatch):
     """Sequences longer than a resident pattern (> 65 536): furthest-reaching sweep / sliding-window kernel,
     incl. the 100 kb and 1 Mb pairs whose distances were captured from the reference."""
@@ -437,7 +440,7 @@ def test_graph_size_limit_is_loud(native):
         LCSgraph(a, b)
 
 
-@pytest.mark.parametrize("path", ["sweep", "band"])
+@pytest.mark.parametrize("path", ["sweep", "band", "mixed"])
 def test_graph_band_vs_oracle(native, path, monkeypatch):
     """Windows beyond 4 095 symbols: the two sweeps, or the sliding-window kernels at all band widths; both signs
     of n - m."""
@@ -457,6 +460,32 @@ def test_graph_band_vs_oracle(native, path, monkeypatch):
     batch.close()
     for i, (a, b) in enumerate(pairs):
         ref = O.lcs_graph(a, b, i)
+        assert res.distance[i] == ref.distance and tuple(res.supremal[i]) == ref.supremal, i
+        assert np.array_equal(res.nodes(i), ref.nodes) and np.array_equal(res.edges(i), ref.edges), i
+    res.close()
+
+
+@pytest.mark.parametrize("path", ["sweep", "band"])
+@pytest.mark.parametrize("alphabet", ["AC", "ACG", "ACGTN", "ACGTNRYKMSWBDHV", "".join(chr(65 + i) for i in range(26)) + "0123456789"])
+def test_graph_long_windows_any_alphabet(native, alphabet, path, monkeypatch):
+    """Long windows over 2 ... 36 symbols (1, 2, 3, 4 and 8 bit planes), lengths off the word grid, reference
+    longer / shorter than the observed sequence, a pure deletion and a pure insertion; graphs against the oracle."""
+    from oracle import oracle as O
+    from algebra_amd.lcs.encoding import encode_pairs
+    use_path(monkeypatch, path)
+    rs = np.random.RandomState(len(alphabet))
+    pairs = []
+    for m, p in ((4099, 0.003), (6001, 0.02), (5055, 0.0005)):
+        a = gen.random_seq(rs, m, alphabet)
+        pairs.append((a, gen.mutate(rs, a, p, p, alphabet)))
+    a = gen.random_seq(rs, 4500, alphabet)
+    pairs += [(a, a[:1000] + a[1033:]), (a[:4100] + a[4131:], a), (a[17:], a), (a, a[:-1])]
+    syms, a_off, a_len, b_off, b_len, n_symbols = encode_pairs(pairs)
+    batch = native.Batch(native.default_context(), syms, a_off, a_len, b_off, b_len, n_symbols)
+    res = batch.graphs()
+    batch.close()
+    for i, (a, b) in enumerate(pairs):
+        ref = O.lcs_graph(a, b)
         assert res.distance[i] == ref.distance and tuple(res.supremal[i]) == ref.supremal, i
         assert np.array_equal(res.nodes(i), ref.nodes) and np.array_equal(res.edges(i), ref.edges), i
     res.close()

@@ -65,6 +65,10 @@ if "c3" in which:
 if "c5" in which:
     sparse = [gen.large_pair({"kind": "few", "seed": 50 + i, "length": 1000000, "events": 20}) for i in range(4)]
     run_pairs("C5(i) 4x1Mb sparse", sparse)
+    t0 = time.time()
+    for a, b in sparse:
+        v, g = extract_sequence(a, b); h = to_hgvs(v, a)
+    print(f"C5(i) extract_sequence+to_hgvs (python facade, str in, HGVS out, per pair): {(time.time()-t0)/4*1e3:.1f} ms", flush=True)
     rs = np.random.RandomState(5)
     a = gen.large_pair({"kind": "mutate", "seed": 5, "length": 1000000, "p": 0.0})[0]
     t0 = time.time(); b = gen.mutate(rs, a, 0.01, 0.01); print("gen", time.time() - t0)
