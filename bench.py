@@ -247,7 +247,7 @@ def main():
         }
         if world == 1 and not args.no_extra:
             out["extra"] = extra_configs(ctx, _native, gen)
-        if not args.no_cpu_baseline:
+        if world == 1 and not args.no_cpu_baseline:                # rank 0 at N = 1 only
             out["cpu_baseline"] = cpu_baseline(data, cells / args.pairs)
         print(json.dumps(out), flush=True)
 
