@@ -62,6 +62,13 @@ def _load():
         "malcs_graphs_canonical_count": (c.c_int, [vp, u64, P(i64)]),
         "malcs_graphs_canonical": (c.c_int, [vp, u64, vp]),
         "malcs_graphs_timing": (c.c_int, [vp, vp]),
+        "malcs_relmatrix_create": (c.c_int, [vp, u64, vp, vp, vp, vp, u32, u32, u32, P(vp)]),
+        "malcs_relmatrix_destroy": (c.c_int, [vp]),
+        "malcs_relmatrix_pending_count": (c.c_int, [vp, P(u64)]),
+        "malcs_relmatrix_pending": (c.c_int, [vp, vp]),
+        "malcs_relmatrix_resolve": (c.c_int, [vp, vp]),
+        "malcs_relmatrix_tiles": (c.c_int, [vp, vp]),
+        "malcs_relmatrix_assemble": (c.c_int, [vp, vp, vp]),
     }
     for name, (res, args) in sig.items():
         fn = getattr(lib, name)          # AttributeError here = header and library disagree
@@ -75,12 +82,12 @@ lib, EXPORTS = _load()
 
 # Handles still open at interpreter exit are released here, in dependency order, while the HIP
 # runtime is still alive (its own teardown runs after Python's).
-_live = {"graphs": weakref.WeakSet(), "batch": weakref.WeakSet(), "ctx": weakref.WeakSet()}
+_live = {"graphs": weakref.WeakSet(), "relmatrix": weakref.WeakSet(), "batch": weakref.WeakSet(), "ctx": weakref.WeakSet()}
 
 
 @atexit.register
 def _close_all():
-    for kind in ("graphs", "batch", "ctx"):
+    for kind in ("graphs", "relmatrix", "batch", "ctx"):
         for obj in list(_live[kind]):
             try:
                 obj.close()
@@ -263,6 +270,66 @@ class Graphs:
     def close(self):
         if self.handle:
             lib.malcs_graphs_destroy(self.handle)
+            self.handle = ctypes.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+class RelationMatrix:
+    """This rank's tiles of the all-vs-all relation matrix on the device (malcs_relmatrix)."""
+
+    def __init__(self, ctx, start, end, key, symmask, tile, rank=0, world=1):
+        self.ctx = ctx
+        start = np.ascontiguousarray(start, dtype=np.int64)
+        end = np.ascontiguousarray(end, dtype=np.int64)
+        key = np.ascontiguousarray(key, dtype=np.uint32)
+        symmask = np.ascontiguousarray(symmask, dtype=np.uint64)
+        self.n = len(start)
+        if not (len(end) == len(key) == len(symmask) == self.n):
+            raise ValueError("per-variant arrays differ in length")
+        self.tile, self.rank, self.world = int(tile), int(rank), int(world)
+        blocks = (self.n + self.tile - 1) // self.tile
+        self.n_tiles = blocks * (blocks + 1) // 2
+        self.per_rank = (self.n_tiles + self.world - 1) // self.world
+        self.handle = ctypes.c_void_p()
+        check(lib.malcs_relmatrix_create(ctx.handle, self.n, ptr(start), ptr(end), ptr(key), ptr(symmask), self.tile,
+                                         self.rank, self.world, ctypes.byref(self.handle)))
+        _live["relmatrix"].add(self)
+
+    def pending(self):
+        """Undecided pairs as an (k, 2) int64 array of (i, j), i < j."""
+        count = ctypes.c_uint64()
+        check(lib.malcs_relmatrix_pending_count(self.handle, ctypes.byref(count)))
+        pairs = np.zeros((count.value, 2), dtype=np.int64)
+        check(lib.malcs_relmatrix_pending(self.handle, ptr(pairs)))
+        return pairs
+
+    def resolve(self, codes):
+        codes = np.ascontiguousarray(codes, dtype=np.uint8)
+        check(lib.malcs_relmatrix_resolve(self.handle, ptr(codes)))
+
+    def tiles(self):
+        out = np.zeros((self.per_rank, self.tile, self.tile), dtype=np.uint8)
+        check(lib.malcs_relmatrix_tiles(self.handle, ptr(out)))
+        return out
+
+    def assemble(self, gathered=None):
+        full = np.zeros((self.n, self.n), dtype=np.uint8)
+        if gathered is not None:
+            gathered = np.ascontiguousarray(gathered, dtype=np.uint8)
+            if gathered.size != self.world * self.per_rank * self.tile * self.tile:
+                raise ValueError("gathered label block has the wrong size")
+        check(lib.malcs_relmatrix_assemble(self.handle, ptr(gathered) if gathered is not None else None, ptr(full)))
+        return full
+
+    def close(self):
+        if self.handle:
+            if self.ctx.handle:
+                lib.malcs_relmatrix_destroy(self.handle)
             self.handle = ctypes.c_void_p()
 
     def __del__(self):

@@ -1,0 +1,256 @@
+// malcs_relation.hip -- kernel family 3: tiles of the all-vs-all relation matrix.
+//
+// Stands in for the parts of graph_based.compare (reference algebra/relations/graph_based.py:33-79) that need no
+// DP, evaluated for whole tiles of the matrix over a list of LCS graphs (the shape of scripts/benchmark.py:38-52):
+//   :51     supremal == supremal                      -> EQUIVALENT   (the caller numbers equal supremals alike: `key`)
+//   :54     supremal.is_disjoint(supremal)            -> DISJOINT     (algebra/variants/variant.py:126-133: intervals
+//           that share no position and are either apart or insert/delete no common symbol; `symmask` holds one bit
+//           per symbol of the inserted sequence)
+//   else    undecided (255): the pair goes to the caller's batch of union-window distances (:57-65, kernel family 1),
+//           whose verdicts (:67-79) come back through malcs_relmatrix_resolve.
+// and for the bookkeeping around them: upper-triangular tiles dealt round-robin to ranks, the label tiles of a rank
+// as one contiguous block for the all-gather, and the assembly of the full matrix (mirror of a label = the relation
+// read from the other side: CONTAINS <-> IS_CONTAINED).
+//
+// One thread per cell, consecutive threads along a tile row: every access to the label tiles is coalesced and the
+// per-variant arrays (a few hundred KB) stay in L2.  HBM-bound and tiny: n^2 / 2 bytes written once, n^2 bytes for
+// the full matrix.
+#include "malcs_internal.hpp"
+#include <algorithm>
+#include <new>
+
+namespace {
+
+constexpr uint8_t EQUIVALENT = 0, CONTAINS = 1, IS_CONTAINED = 2, DISJOINT = 4, UNDECIDED = 255;
+
+// tile number idx (row-major over the upper triangle of a blocks x blocks grid) -> (block row, block col)
+__host__ __device__ inline void tile_coords(uint32_t idx, uint32_t blocks, uint32_t &bi, uint32_t &bj)
+{
+    uint32_t row = 0, left = idx;
+    while (left >= blocks - row) { left -= blocks - row; row++; }
+    bi = row; bj = row + left;
+}
+__host__ __device__ inline uint32_t tile_index(uint32_t bi, uint32_t bj, uint32_t blocks)
+{
+    return bi * blocks - bi * (bi - 1u) / 2u + (bj - bi);
+}
+
+// grid (tiles of this rank, cells of a tile / 256)
+__global__ void __launch_bounds__(256)
+k_relation_tiles(uint32_t n, const int64_t *__restrict__ start, const int64_t *__restrict__ end,
+                 const uint32_t *__restrict__ key, const uint64_t *__restrict__ symmask, uint32_t tile, uint32_t blocks,
+                 uint32_t rank, uint32_t world, uint8_t *__restrict__ labels, unsigned long long *__restrict__ n_pending)
+{
+    const uint32_t t = blockIdx.x, cell = blockIdx.y * 256u + threadIdx.x;
+    if (cell >= tile * tile) return;
+    uint32_t bi, bj;
+    tile_coords(t * world + rank, blocks, bi, bj);
+    const uint32_t r = cell / tile, c = cell % tile, i = bi * tile + r, j = bj * tile + c;
+    uint8_t label = EQUIVALENT;                                  // cells outside the matrix and the mirrored half of
+    if (i < n && j < n && !(bi == bj && r > c)) {                 // a diagonal tile stay 0
+        const int64_t si = start[i], ei = end[i], sj = start[j], ej = end[j];
+        if (key[i] == key[j]) label = EQUIVALENT;                                            // :51
+        else if (!(sj < ei && si < ej) && (sj > ei || si > ej || (symmask[i] & symmask[j]) == 0)) label = DISJOINT;   // :54
+        else label = UNDECIDED;
+    }
+    labels[(size_t)t * tile * tile + cell] = label;
+    // one atomic per wave
+    const uint64_t votes = __ballot(label == UNDECIDED);
+    if (votes && (threadIdx.x & 63u) == (uint32_t)__builtin_ctzll(votes)) atomicAdd(n_pending, (unsigned long long)__builtin_popcountll(votes));
+}
+
+__global__ void __launch_bounds__(256)
+k_relation_collect(const uint8_t *__restrict__ labels, uint64_t n_cells, unsigned long long *__restrict__ cursor,
+                   uint64_t cap, uint64_t *__restrict__ cells)
+{
+    const uint64_t cell = (uint64_t)blockIdx.x * 256u + threadIdx.x;
+    if (cell >= n_cells || labels[cell] != UNDECIDED) return;
+    const unsigned long long slot = atomicAdd(cursor, 1ull);
+    if (slot < cap) cells[slot] = cell;
+}
+
+__global__ void __launch_bounds__(256)
+k_relation_resolve(uint8_t *__restrict__ labels, const uint64_t *__restrict__ cells, const uint8_t *__restrict__ codes, uint64_t count)
+{
+    const uint64_t k = (uint64_t)blockIdx.x * 256u + threadIdx.x;
+    if (k < count) labels[cells[k]] = codes[k];
+}
+
+// full[i][j]: grid (n, ceil(n / 256)); the tile of (min, max) holds the label, read from the other side when i > j
+__global__ void __launch_bounds__(256)
+k_relation_assemble(uint32_t n, uint32_t tile, uint32_t blocks, uint32_t world, uint32_t per_rank,
+                    const uint8_t *__restrict__ gathered, uint8_t *__restrict__ full)
+{
+    const uint32_t i = blockIdx.x, j = blockIdx.y * 256u + threadIdx.x;
+    if (j >= n) return;
+    uint8_t v = EQUIVALENT;
+    if (i != j) {
+        const uint32_t lo = min(i, j), hi = max(i, j);
+        const uint32_t idx = tile_index(lo / tile, hi / tile, blocks);
+        const size_t slot = (size_t)(idx % world) * per_rank + idx / world;
+        v = gathered[slot * tile * tile + (size_t)(lo % tile) * tile + hi % tile];
+        if (i > j) v = v == CONTAINS ? IS_CONTAINED : (v == IS_CONTAINED ? CONTAINS : v);
+    }
+    full[(size_t)i * n + j] = v;
+}
+
+template <typename T> struct dev {
+    T *p = nullptr;
+    ~dev() { if (p) hipFree(p); }
+    int alloc(size_t count) { return hipMalloc(&p, (count ? count : 1) * sizeof(T)) == hipSuccess ? 0 : -1; }
+};
+
+}  // namespace
+
+struct malcs_relmatrix {
+    malcs_ctx *ctx = nullptr;
+    uint32_t n = 0, tile = 0, blocks = 0, rank = 0, world = 1, n_tiles = 0, mine = 0, per_rank = 0;
+    dev<uint8_t> labels;               // this rank's tiles, per_rank x tile x tile (unused slots zero)
+    dev<uint64_t> cells;               // undecided cells (index into labels)
+    uint64_t n_pending = 0;
+    std::vector<uint64_t> host_cells;
+};
+
+extern "C" {
+
+int malcs_relmatrix_create(malcs_ctx *ctx, uint64_t n, const int64_t *start, const int64_t *end, const uint32_t *key,
+                           const uint64_t *symmask, uint32_t tile, uint32_t rank, uint32_t world, malcs_relmatrix **out)
+{
+    if (!out) { malcs_set_error("out is NULL"); return MALCS_ERR_ARG; }
+    *out = nullptr;
+    if (!ctx || (n && (!start || !end || !key || !symmask)) || tile == 0 || tile > 2048 || world == 0 || rank >= world ||
+        n > 0x7fffffffull) {
+        malcs_set_error("bad argument to malcs_relmatrix_create");
+        return MALCS_ERR_ARG;
+    }
+    MALCS_HIP(hipSetDevice(ctx->device));
+    hipStream_t st = ctx->stream;
+    malcs_relmatrix *h = new (std::nothrow) malcs_relmatrix();
+    if (!h) { malcs_set_error("out of host memory"); return MALCS_ERR_NOMEM; }
+    h->ctx = ctx; h->n = (uint32_t)n; h->tile = tile; h->rank = rank; h->world = world;
+    h->blocks = (uint32_t)((n + tile - 1) / tile);
+    const uint64_t n_tiles = (uint64_t)h->blocks * (h->blocks + 1) / 2;
+    if (n_tiles > 0x7fffffffull) { delete h; malcs_set_error("too many tiles"); return MALCS_ERR_TOO_LONG; }
+    h->n_tiles = (uint32_t)n_tiles;
+    h->mine = h->n_tiles > rank ? (h->n_tiles - rank + world - 1) / world : 0;
+    h->per_rank = (h->n_tiles + world - 1) / world;
+    const size_t tile_cells = (size_t)tile * tile, n_cells = (size_t)h->per_rank * tile_cells;
+    dev<int64_t> d_start, d_end;
+    dev<uint32_t> d_key;
+    dev<uint64_t> d_mask;
+    dev<unsigned long long> d_count;
+    int rc = MALCS_OK;
+    do {
+        if (h->labels.alloc(n_cells) || d_start.alloc(n) || d_end.alloc(n) || d_key.alloc(n) || d_mask.alloc(n) || d_count.alloc(2)) {
+            malcs_set_error("device allocation failed (%llu label bytes)", (unsigned long long)n_cells);
+            rc = MALCS_ERR_NOMEM; break;
+        }
+#define RM_HIP(call) { hipError_t e_ = (call); if (e_ != hipSuccess) { malcs_set_error("%s failed: %s", #call, hipGetErrorString(e_)); rc = MALCS_ERR_HIP; break; } }
+        RM_HIP(hipMemsetAsync(h->labels.p, 0, n_cells ? n_cells : 1, st));
+        RM_HIP(hipMemsetAsync(d_count.p, 0, 16, st));
+        if (n) {
+            RM_HIP(hipMemcpyAsync(d_start.p, start, n * 8, hipMemcpyHostToDevice, st));
+            RM_HIP(hipMemcpyAsync(d_end.p, end, n * 8, hipMemcpyHostToDevice, st));
+            RM_HIP(hipMemcpyAsync(d_key.p, key, n * 4, hipMemcpyHostToDevice, st));
+            RM_HIP(hipMemcpyAsync(d_mask.p, symmask, n * 8, hipMemcpyHostToDevice, st));
+        }
+        if (h->mine) {
+            hipLaunchKernelGGL(k_relation_tiles, dim3(h->mine, (uint32_t)((tile_cells + 255) / 256)), dim3(256), 0, st, h->n, d_start.p,
+                               d_end.p, d_key.p, d_mask.p, tile, h->blocks, rank, world, h->labels.p, d_count.p);
+            RM_HIP(hipGetLastError());
+        }
+        unsigned long long count = 0;
+        RM_HIP(hipMemcpyAsync(&count, d_count.p, 8, hipMemcpyDeviceToHost, st));
+        RM_HIP(hipStreamSynchronize(st));
+        h->n_pending = count;
+        if (count) {
+            if (h->cells.alloc(count)) { malcs_set_error("device allocation failed (%llu undecided pairs)", count); rc = MALCS_ERR_NOMEM; break; }
+            const uint64_t scan = (uint64_t)h->mine * tile_cells;
+            hipLaunchKernelGGL(k_relation_collect, dim3((uint32_t)((scan + 255) / 256)), dim3(256), 0, st, h->labels.p, scan, d_count.p + 1,
+                               (uint64_t)count, h->cells.p);
+            RM_HIP(hipGetLastError());
+            h->host_cells.resize(count);
+            RM_HIP(hipMemcpyAsync(h->host_cells.data(), h->cells.p, count * 8, hipMemcpyDeviceToHost, st));
+            RM_HIP(hipStreamSynchronize(st));
+        }
+    } while (0);
+    if (rc) { delete h; return rc; }
+    *out = h;
+    return MALCS_OK;
+}
+
+int malcs_relmatrix_destroy(malcs_relmatrix *h) { delete h; return MALCS_OK; }
+
+int malcs_relmatrix_pending_count(const malcs_relmatrix *h, uint64_t *count)
+{
+    if (!h || !count) { malcs_set_error("NULL argument"); return MALCS_ERR_ARG; }
+    *count = h->n_pending;
+    return MALCS_OK;
+}
+
+int malcs_relmatrix_pending(const malcs_relmatrix *h, int64_t *pairs2)
+{
+    if (!h || (h->n_pending && !pairs2)) { malcs_set_error("NULL argument"); return MALCS_ERR_ARG; }
+    const uint64_t tile_cells = (uint64_t)h->tile * h->tile;
+    for (uint64_t k = 0; k < h->n_pending; k++) {
+        const uint64_t cell = h->host_cells[k], t = cell / tile_cells, in = cell % tile_cells;
+        uint32_t bi, bj;
+        tile_coords((uint32_t)(t * h->world + h->rank), h->blocks, bi, bj);
+        pairs2[2 * k] = (int64_t)bi * h->tile + (int64_t)(in / h->tile);
+        pairs2[2 * k + 1] = (int64_t)bj * h->tile + (int64_t)(in % h->tile);
+    }
+    return MALCS_OK;
+}
+
+int malcs_relmatrix_resolve(malcs_relmatrix *h, const uint8_t *codes)
+{
+    if (!h || (h->n_pending && !codes)) { malcs_set_error("NULL argument"); return MALCS_ERR_ARG; }
+    if (!h->n_pending) return MALCS_OK;
+    for (uint64_t k = 0; k < h->n_pending; k++)
+        if (codes[k] > DISJOINT) { malcs_set_error("code %u of pair %llu is not a relation", codes[k], (unsigned long long)k); return MALCS_ERR_ARG; }
+    MALCS_HIP(hipSetDevice(h->ctx->device));
+    hipStream_t st = h->ctx->stream;
+    dev<uint8_t> d_codes;
+    if (d_codes.alloc(h->n_pending)) { malcs_set_error("device allocation failed"); return MALCS_ERR_NOMEM; }
+    MALCS_HIP(hipMemcpyAsync(d_codes.p, codes, h->n_pending, hipMemcpyHostToDevice, st));
+    hipLaunchKernelGGL(k_relation_resolve, dim3((uint32_t)((h->n_pending + 255) / 256)), dim3(256), 0, st, h->labels.p, h->cells.p,
+                       d_codes.p, h->n_pending);
+    MALCS_HIP(hipGetLastError());
+    MALCS_HIP(hipStreamSynchronize(st));
+    return MALCS_OK;
+}
+
+int malcs_relmatrix_tiles(const malcs_relmatrix *h, uint8_t *labels)
+{
+    if (!h || !labels) { malcs_set_error("NULL argument"); return MALCS_ERR_ARG; }
+    MALCS_HIP(hipSetDevice(h->ctx->device));
+    const size_t bytes = (size_t)h->per_rank * h->tile * h->tile;
+    if (bytes) MALCS_HIP(hipMemcpyAsync(labels, h->labels.p, bytes, hipMemcpyDeviceToHost, h->ctx->stream));
+    MALCS_HIP(hipStreamSynchronize(h->ctx->stream));
+    return MALCS_OK;
+}
+
+int malcs_relmatrix_assemble(malcs_relmatrix *h, const uint8_t *gathered, uint8_t *full)
+{
+    if (!h || (h->n && !full) || (h->world > 1 && !gathered)) { malcs_set_error("NULL argument"); return MALCS_ERR_ARG; }
+    if (!h->n) return MALCS_OK;
+    MALCS_HIP(hipSetDevice(h->ctx->device));
+    hipStream_t st = h->ctx->stream;
+    const size_t bytes = (size_t)h->world * h->per_rank * h->tile * h->tile;
+    dev<uint8_t> d_gathered, d_full;
+    const uint8_t *src = h->labels.p;
+    if (d_full.alloc((size_t)h->n * h->n)) { malcs_set_error("device allocation failed (%u x %u labels)", h->n, h->n); return MALCS_ERR_NOMEM; }
+    if (gathered) {
+        if (d_gathered.alloc(bytes)) { malcs_set_error("device allocation failed (%llu gathered label bytes)", (unsigned long long)bytes); return MALCS_ERR_NOMEM; }
+        MALCS_HIP(hipMemcpyAsync(d_gathered.p, gathered, bytes, hipMemcpyHostToDevice, st));
+        src = d_gathered.p;
+    }
+    hipLaunchKernelGGL(k_relation_assemble, dim3(h->n, (h->n + 255u) / 256u), dim3(256), 0, st, h->n, h->tile, h->blocks, h->world,
+                       h->per_rank, src, d_full.p);
+    MALCS_HIP(hipGetLastError());
+    MALCS_HIP(hipMemcpyAsync(full, d_full.p, (size_t)h->n * h->n, hipMemcpyDeviceToHost, st));
+    MALCS_HIP(hipStreamSynchronize(st));
+    return MALCS_OK;
+}
+
+}  // extern "C"

@@ -153,6 +153,34 @@ int malcs_graphs_canonical(malcs_graphs *graphs, uint64_t i, int64_t *variants4)
  * out[0] forward DP kernel, out[1] reach/extract kernel (HIP events), out[2] D2H + host graph build */
 int malcs_graphs_timing(const malcs_graphs *graphs, float *out3);
 
+/* ---- kernel family 3: tiles of the all-vs-all relation matrix -----------------------------------
+ * Stands in for graph_based.compare (algebra/relations/graph_based.py:33-79) over all pairs of a list of n LCS graphs
+ * (the loop of scripts/benchmark.py:38-52), minus its one DP, which stays with kernel family 1:
+ *   create    evaluates the O(1) tests for this rank's tiles on the device: key[i] == key[j] -> EQUIVALENT (:51; the
+ *             caller gives equal supremal variants equal keys), Variant.is_disjoint (algebra/variants/variant.py:126-133)
+ *             on [start, end) and the symbol bit masks -> DISJOINT (:54); everything else is undecided.
+ *             Tiles are tile x tile cells of the upper triangle, numbered row-major and dealt round-robin:
+ *             tile number t * world + rank is this rank's tile t.
+ *   pending   the undecided pairs (i < j), 2 int64 each.  The caller computes edit_distance over their union windows
+ *             (:57-65, malcs_edit_distance_batch), decides :67-79 and hands one relation code per pair to
+ *   resolve   (codes follow the reference's Relation order: 0 equivalent, 1 contains, 2 is_contained, 3 overlap,
+ *             4 disjoint).
+ *   tiles     this rank's label tiles, ceil(n_tiles / world) x tile x tile bytes: the block each rank contributes to
+ *             the all-gather (RCCL; the only inter-GPU traffic of the path).
+ *   assemble  the full n x n matrix from the gathered blocks (world x ceil(n_tiles / world) x tile x tile, rank-major;
+ *             NULL when world == 1): label[j][i] is label[i][j] read from the other side.
+ * A symbol mask has one bit per distinct symbol of the variant's inserted sequence; with more than 64 symbols the
+ * caller may fold them (then DISJOINT is under-reported and such pairs merely arrive in `pending`). */
+typedef struct malcs_relmatrix malcs_relmatrix;
+int malcs_relmatrix_create(malcs_ctx *ctx, uint64_t n, const int64_t *start, const int64_t *end, const uint32_t *key,
+                           const uint64_t *symmask, uint32_t tile, uint32_t rank, uint32_t world, malcs_relmatrix **out);
+int malcs_relmatrix_destroy(malcs_relmatrix *m);
+int malcs_relmatrix_pending_count(const malcs_relmatrix *m, uint64_t *count);
+int malcs_relmatrix_pending(const malcs_relmatrix *m, int64_t *pairs2);
+int malcs_relmatrix_resolve(malcs_relmatrix *m, const uint8_t *codes);
+int malcs_relmatrix_tiles(const malcs_relmatrix *m, uint8_t *labels);
+int malcs_relmatrix_assemble(malcs_relmatrix *m, const uint8_t *gathered, uint8_t *full);
+
 #ifdef __cplusplus
 }
 #endif

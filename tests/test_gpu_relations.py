@@ -60,6 +60,48 @@ def test_variant_and_supremal_based_relations():
             assert supremal_based.compare(case["reference"], sup[i], sup[j]) == codes[case["supremal_labels_12"][i][j]]
 
 
+@pytest.mark.parametrize("n,tile,world", [(1, 4, 1), (37, 8, 1), (300, 16, 3), (1000, 256, 2), (513, 64, 8), (700, 7, 5)])
+def test_relation_tile_kernels(n, tile, world):
+    """Kernel family 3 through the C-ABI against the numpy restatement: pre-filter labels and undecided pairs of
+    every rank's tiles, scatter of verdicts, assembly of the full matrix from the gathered blocks."""
+    from algebra_amd import _native
+    from util import HostTiles
+    rs = np.random.RandomState(n + tile)
+    start = rs.randint(0, 4 * n, n).astype(np.int64)
+    end = start + rs.randint(0, 12, n)
+    symmask = rs.randint(0, 16, n).astype(np.uint64) | (rs.randint(0, 2, n).astype(np.uint64) << np.uint64(63))
+    key = np.arange(n, dtype=np.uint32)
+    twins = rs.randint(0, n, max(1, n // 10))
+    key[twins] = key[(twins * 7) % n]; start[twins] = start[(twins * 7) % n]; end[twins] = end[(twins * 7) % n]
+    symmask[twins] = symmask[(twins * 7) % n]
+    ctx = _native.default_context()
+    dev = [_native.RelationMatrix(ctx, start, end, key, symmask, tile, r, world) for r in range(world)]
+    host = [HostTiles(start, end, key, symmask, tile, r, world) for r in range(world)]
+    blocks_d, blocks_h = [], []
+    for d, h in zip(dev, host):
+        assert np.array_equal(d.tiles(), h.tiles())
+        pd, ph = d.pending(), h.pending()
+        assert sorted(map(tuple, pd.tolist())) == sorted(map(tuple, ph.tolist()))
+        assert (pd[:, 0] < pd[:, 1]).all()
+        codes = {(i, j): int((i * 31 + j) % 5) for i, j in ph.tolist()}
+        d.resolve(np.array([codes[(i, j)] for i, j in pd.tolist()], np.uint8))
+        h.resolve(np.array([codes[(i, j)] for i, j in ph.tolist()], np.uint8))
+        assert np.array_equal(d.tiles(), h.tiles())
+        blocks_d.append(d.tiles()); blocks_h.append(h.tiles())
+    gathered = np.concatenate(blocks_d) if world > 1 else None
+    want = host[0].assemble(np.concatenate(blocks_h) if world > 1 else None)
+    for d in dev:
+        assert np.array_equal(d.assemble(gathered), want)
+        d.close()
+    if n > 1:
+        with pytest.raises(_native.MalcsError):
+            bad = _native.RelationMatrix(ctx, start, end, key, symmask, tile, 0, 1)
+            try:
+                bad.resolve(np.full(len(bad.pending()) or 1, 9, np.uint8)) if len(bad.pending()) else (_ for _ in ()).throw(_native.MalcsError("none"))
+            finally:
+                bad.close()
+
+
 @pytest.mark.parametrize("tile", [16, 256])
 def test_compare_matrix(tile):
     """C4 in small: supremal graphs on the GPU, then the tiled all-vs-all matrix."""

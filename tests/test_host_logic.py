@@ -5,6 +5,7 @@ from the CPU oracle (allowed in tests); distances for the matrix come from the o
 
 import numpy as np
 import pytest
+from util import HostTiles
 
 from conftest import load_golden
 from oracle import oracle as O
@@ -94,7 +95,7 @@ def test_compare_matrix_single_rank(tile):
     from algebra_amd.relations import compare_matrix
     for case in SEQS["matrices"]:
         stats = {}
-        labels = compare_matrix(case["reference"], matrix_inputs(case), tile=tile, distance_fn=oracle_distances, stats=stats)
+        labels = compare_matrix(case["reference"], matrix_inputs(case), tile=tile, distance_fn=oracle_distances, stats=stats, tiles_cls=HostTiles)
         assert labels.tolist() == case["labels"]
         assert 0 < stats["dp_pairs"] < len(case["labels"]) ** 2 // 2
 
@@ -108,7 +109,7 @@ def _rank_main(rank, world, port, out):
         from algebra_amd.relations import compare_matrix
         case = SEQS["matrices"][0]
         stats = {}
-        labels = compare_matrix(case["reference"], matrix_inputs(case), tile=8, distance_fn=oracle_distances, stats=stats)
+        labels = compare_matrix(case["reference"], matrix_inputs(case), tile=8, distance_fn=oracle_distances, stats=stats, tiles_cls=HostTiles)
         out.put((rank, labels.tolist() == case["labels"], stats["tiles"]))
     finally:
         dist.destroy_process_group()

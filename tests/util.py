@@ -73,3 +73,72 @@ def assert_graph(rec, got):
         assert got == want
     else:
         assert digest(got) == sha
+
+
+class HostTiles:
+    """numpy restatement of kernel family 3 (csrc/malcs_relation.hip) with the interface of
+    `_native.RelationMatrix` -- TEST INFRASTRUCTURE: the CPU tests inject it into `compare_matrix`
+    (no GPU there), the GPU tests check the kernels against it."""
+
+    MIRROR = None
+
+    def __init__(self, start, end, key, symmask, tile, rank=0, world=1):
+        import numpy as np
+        self.np = np
+        self.n, self.tile, self.rank, self.world = len(start), tile, rank, world
+        blocks = (self.n + tile - 1) // tile
+        self.all_tiles = [(bi, bj) for bi in range(blocks) for bj in range(bi, blocks)]
+        self.mine = self.all_tiles[rank::world]
+        self.per_rank = (len(self.all_tiles) + world - 1) // world
+        self.labels = np.zeros((self.per_rank, tile, tile), dtype=np.uint8)
+        self.cells = []
+        n = self.n
+        for t, (bi, bj) in enumerate(self.mine):
+            rows = np.arange(bi * tile, min(n, (bi + 1) * tile))
+            cols = np.arange(bj * tile, min(n, (bj + 1) * tile))
+            s_r, e_r = start[rows][:, None], end[rows][:, None]
+            s_c, e_c = start[cols][None, :], end[cols][None, :]
+            overlapping = (s_c < e_r) & (s_r < e_c)
+            apart = (s_c > e_r) | (s_r > e_c)
+            shared = (symmask[rows][:, None] & symmask[cols][None, :]) != 0
+            lab = np.full((len(rows), len(cols)), 255, dtype=np.uint8)
+            lab[~overlapping & (apart | ~shared)] = 4
+            lab[key[rows][:, None] == key[cols][None, :]] = 0
+            if bi == bj:
+                lab[np.tril_indices(len(rows), -1)] = 0
+            self.labels[t, :len(rows), :len(cols)] = lab
+            for r, c in zip(*np.nonzero(lab == 255)):
+                self.cells.append((t, int(r), int(c), int(rows[r]), int(cols[c])))
+
+    def pending(self):
+        return self.np.array([[i, j] for *_, i, j in self.cells], dtype=self.np.int64).reshape(-1, 2)
+
+    def resolve(self, codes):
+        for (t, r, c, _, _), code in zip(self.cells, codes):
+            self.labels[t, r, c] = code
+
+    def tiles(self):
+        return self.labels.copy()
+
+    def assemble(self, gathered=None):
+        np = self.np
+        mirror = np.array([0, 2, 1, 3, 4], dtype=np.uint8)
+        n, tile, world = self.n, self.tile, self.world
+        blocks = self.labels[None] if gathered is None else np.asarray(gathered).reshape(world, self.per_rank, tile, tile)
+        full = np.zeros((n, n), dtype=np.uint8)
+        for r in range(world):
+            for t, (bi, bj) in enumerate(self.all_tiles[r::world]):
+                r0, c0 = bi * tile, bj * tile
+                h, w = min(tile, n - r0), min(tile, n - c0)
+                block = blocks[r, t, :h, :w]
+                if bi == bj:
+                    upper = np.triu(block, 1)
+                    full[r0:r0 + h, c0:c0 + w] = upper + mirror[upper].T * np.tri(h, w, -1, dtype=np.uint8)
+                else:
+                    full[r0:r0 + h, c0:c0 + w] = block
+                    full[c0:c0 + w, r0:r0 + h] = mirror[block].T
+        np.fill_diagonal(full, 0)
+        return full
+
+    def close(self):
+        pass
