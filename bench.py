@@ -119,6 +119,7 @@ def extra_configs(ctx, _native, gen):
     case = gen.matrix_case(seed=4, length=100000, n_clusters=50, per_cluster=100, width=200)
     t0 = time.perf_counter()
     graphs = LCSgraph.from_variant_batch(case["reference"], [[Variant(*v)] for v in case["variants"]], ctx=ctx)
+    t_graphs = time.perf_counter() - t0
     compare_matrix(case["reference"], graphs)                  # warm-up (code objects, atom masks of the graphs)
     t1 = time.perf_counter()
     stats = {}
@@ -126,7 +127,7 @@ def extra_configs(ctx, _native, gen):
     t2 = time.perf_counter()
     pairs = len(graphs) * (len(graphs) - 1) // 2
     out["c4_relation_matrix"] = {"variants": len(graphs), "pairs": pairs, "relations_per_s": round(pairs / (t2 - t1), 1),
-                                 "pairs_reaching_dp": stats["dp_pairs"], "supremal_graphs_s": round(t1 - t0, 3),
+                                 "pairs_reaching_dp": stats["dp_pairs"], "supremal_graphs_s": round(t_graphs, 3),
                                  "matrix_s": round(t2 - t1, 4),
                                  "stages_ms": {k[8:]: round(v * 1e3, 2) for k, v in stats.items() if k.startswith("seconds_")}}
     return out

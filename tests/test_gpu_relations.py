@@ -257,3 +257,39 @@ def test_atom_masks_equal_atom_sets():
     c = a[:300] + "ACGT" + a[300:]
     g1, g2 = LCSgraph.batch([(a, b), (a, c)])
     assert g1.is_disjoint(g2) == g1.uniq_atomics().isdisjoint(g2.uniq_atomics())
+
+
+def _matrix_rank(rank, world, port, out):
+    import os
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), MALCS_DEVICE="0")
+    import torch.distributed as dist
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from algebra_amd.lcs import LCSgraph
+        from algebra_amd.relations import compare_matrix
+        from algebra_amd.variants import Variant
+        case = SEQS["matrices"][0]
+        graphs = LCSgraph.from_variant_batch(case["reference"], [[Variant(*v)] for v in case["variants"]])
+        stats = {}
+        labels = compare_matrix(case["reference"], graphs, tile=8, stats=stats)
+        out.put((rank, labels.tolist() == case["labels"], stats["tiles"], stats["dp_pairs"]))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_compare_matrix_two_ranks_on_the_device():
+    """The N > 1 product path end to end: two ranks (both on GPU 0, gloo for the rendezvous since one card cannot
+    host two RCCL ranks), each with its own tiles on the device, all-gather of the label blocks, device assembly."""
+    import torch.multiprocessing as mp
+    ctx = mp.get_context("spawn")
+    out = ctx.Queue()
+    port = 31500 + np.random.RandomState().randint(0, 2000)
+    procs = [ctx.Process(target=_matrix_rank, args=(r, 2, port, out)) for r in range(2)]
+    for p in procs:
+        p.start()
+    results = sorted(out.get(timeout=150) for _ in procs)
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    assert [r[1] for r in results] == [True, True]
+    assert abs(results[0][2] - results[1][2]) <= 1 and results[0][3] + results[1][3] > 0
