@@ -70,7 +70,8 @@ void order_runs(std::vector<run> &out, int64_t m, int64_t n)
 {
     const int64_t delta = n - m, adelta = delta < 0 ? -delta : delta;
     struct keyed { int64_t level, it, grp, dk, row; run r; };
-    std::vector<keyed> k;
+    static thread_local std::vector<keyed> k;             // reused by the worker thread from pair to pair
+    k.clear();
     k.reserve(out.size());
     for (const run &r : out) {
         const int64_t re = r.row + r.len, ce = r.col + r.len, diag = r.col - r.row;
@@ -115,27 +116,45 @@ bool runs_from_events(event_span ev, int64_t m, int64_t n, std::vector<run> &out
 // ---- _build_graph -------------------------------------------------------------------------------
 struct gedge { int32_t child; int64_t start, end, from, to; };
 
+// Working state of one graph under construction.  A worker thread keeps one of these and clears it per pair: node
+// fields in flat arrays, the out-edges of all nodes as linked lists through one pool (append order = Node.edges
+// order), so that a batch of 100 000 small graphs costs no allocation per node.
 struct builder {
     // node arrays (Node.row/.col/.length/._length/._incoming, lcs_graph.py:36-44)
     std::vector<int64_t> row, col, length, wlen, incoming;
-    std::vector<std::vector<gedge>> out;
+    std::vector<int32_t> head, tail;            // first / last pool entry of the node's edges, -1: none
+    std::vector<gedge> pool;
+    std::vector<int32_t> next;
+    std::vector<int32_t> cur, below, id, order;
 
-    void reserve(size_t k)
+    void clear()
     {
-        row.reserve(k); col.reserve(k); length.reserve(k); wlen.reserve(k); incoming.reserve(k); out.reserve(k);
+        row.clear(); col.clear(); length.clear(); wlen.clear(); incoming.clear(); head.clear(); tail.clear();
+        pool.clear(); next.clear(); cur.clear(); below.clear(); id.clear(); order.clear();
     }
     int32_t add(int64_t r, int64_t c, int64_t l)
     {
         row.push_back(r); col.push_back(c); length.push_back(l); wlen.push_back(l); incoming.push_back(0);
-        out.emplace_back();
+        head.push_back(-1); tail.push_back(-1);
         return (int32_t)row.size() - 1;
+    }
+    bool no_edges(int32_t node) const { return head[node] < 0; }
+    void push(int32_t node, const gedge &e)
+    {
+        const int32_t slot = (int32_t)pool.size();
+        pool.push_back(e); next.push_back(-1);
+        if (tail[node] < 0) head[node] = slot; else next[tail[node]] = slot;
+        tail[node] = slot;
+    }
+    void copy_edges(int32_t dst, int32_t src)
+    {
+        for (int32_t i = head[src]; i >= 0; i = next[i]) { const gedge e = pool[i]; push(dst, e); }
     }
 };
 
-void build_graph(int64_t m, int64_t n, int64_t shift, const std::vector<run> &runs, int64_t n_levels, pair_graph &G)
+void build_graph(builder &B, int64_t m, int64_t n, int64_t shift, const std::vector<run> &runs, int64_t n_levels, pair_graph &G)
 {
-    builder B;
-    B.reserve(runs.size() * 2 + 8);
+    B.clear();
     int32_t source, sink;
     const bool degenerate = runs.empty() || n_levels == 0;
     if (degenerate) {                                                    // :370-377
@@ -144,7 +163,7 @@ void build_graph(int64_t m, int64_t n, int64_t shift, const std::vector<run> &ru
             G.supremal[0] = G.supremal[1] = G.supremal[2] = G.supremal[3] = 0;
         } else {
             sink = B.add(m, n, 0);                                       // sink keeps unshifted coordinates
-            B.out[source].push_back({sink, shift, shift + m, 0, n});
+            B.push(source, {sink, shift, shift + m, 0, n});
             G.supremal[0] = shift; G.supremal[1] = shift + m; G.supremal[2] = 0; G.supremal[3] = n;
         }
     } else {
@@ -160,7 +179,8 @@ void build_graph(int64_t m, int64_t n, int64_t shift, const std::vector<run> &ru
         } else {
             sink = B.add(m + shift, n + shift, 1);
         }
-        std::vector<int32_t> cur{sink}, below;
+        std::vector<int32_t> &cur = B.cur, &below = B.below;
+        cur.push_back(sink);
 
         int64_t max_sink = 0;
         for (int64_t depth = n_levels + 1; depth > 1; depth--) {         // depth == len_lcs_nodes, :389
@@ -172,7 +192,7 @@ void build_graph(int64_t m, int64_t n, int64_t shift, const std::vector<run> &ru
                 int64_t stride = idle;
                 if (cur.size() == 1) {
                     const int32_t node = cur[0];
-                    if (node != sink && B.out[node].empty()) { cur.clear(); }
+                    if (node != sink && B.no_edges(node)) { cur.clear(); }
                     else { stride = std::min<int64_t>(idle, B.wlen[node] - 1); B.wlen[node] -= stride; }
                 }
                 if (stride > 0) { depth -= stride - 1; continue; }
@@ -184,26 +204,26 @@ void build_graph(int64_t m, int64_t n, int64_t shift, const std::vector<run> &ru
             unread = first;
             for (size_t qi = 0; qi < cur.size(); qi++) {                 // pop(0) in order, :390-391
                 const int32_t node = cur[qi];
-                if (node != sink && B.out[node].empty()) continue;       // :393-394
+                if (node != sink && B.no_edges(node)) continue;          // :393-394
                 size_t idx_parent = 0;
+                const int64_t nr = B.row[node] + B.wlen[node], nc = B.col[node] + B.wlen[node];
                 for (size_t idx = 0; idx < below.size(); idx++) {        // :397
                     const int32_t parent = below[idx];
                     const int64_t pr = B.row[parent] + B.wlen[parent], pc = B.col[parent] + B.wlen[parent];
-                    const int64_t nr = B.row[node] + B.wlen[node], nc = B.col[node] + B.wlen[node];
                     if (pr < nr && pc < nc) {                            // :398 strict dominance of the ends
                         const gedge e{node, pr, nr - 1, pc - shift, nc - 1 - shift};    // :399-400
                         if (node == sink) max_sink = std::max(max_sink, nr - 1);         // :402-403
                         if (B.incoming[parent] == depth) {               // :405-412 split the parent
                             const int32_t split = B.add(B.row[parent], B.col[parent], B.length[parent]);
                             B.wlen[split] = B.wlen[parent];
-                            B.out[split] = B.out[parent];
-                            B.out[split].push_back(e);
+                            B.copy_edges(split, parent);
+                            B.push(split, e);
                             below[idx] = split;
                             B.row[parent] += B.wlen[parent];
                             B.col[parent] += B.wlen[parent];
                             B.length[parent] -= B.wlen[parent];
                         } else {
-                            B.out[parent].push_back(e);                  // :414
+                            B.push(parent, e);                           // :414
                         }
                         idx_parent = idx + 1;                            // :416
                     }
@@ -224,17 +244,17 @@ void build_graph(int64_t m, int64_t n, int64_t shift, const std::vector<run> &ru
         else source = B.add(shift, shift, 0);
         for (size_t qi = first; qi < l0.size(); qi++) {                  // :434-445
             const int32_t node = l0[qi];
-            if (node != sink && B.out[node].empty()) continue;
+            if (node != sink && B.no_edges(node)) continue;
             const int64_t nr = B.row[node] + B.wlen[node], nc = B.col[node] + B.wlen[node];
             if (B.row[source] < nr && B.col[source] < nc) {
                 if (node == sink) max_sink = std::max(max_sink, nr - 1);
-                B.out[source].push_back({node, B.row[source], nr - 1, B.col[source] - shift, nc - 1 - shift});
+                B.push(source, {node, B.row[source], nr - 1, B.col[source] - shift, nc - 1 - shift});
             }
         }
         int64_t source_offset = shift;                                   // :447-451
-        if (!B.out[source].empty()) {
-            source_offset = B.out[source][0].start;
-            for (const gedge &e : B.out[source]) source_offset = std::min(source_offset, e.start);
+        if (!B.no_edges(source)) {
+            source_offset = B.pool[B.head[source]].start;
+            for (int32_t i = B.head[source]; i >= 0; i = B.next[i]) source_offset = std::min(source_offset, B.pool[i].start);
         }
         source_offset -= shift;
         B.row[source] += source_offset;
@@ -248,14 +268,15 @@ void build_graph(int64_t m, int64_t n, int64_t shift, const std::vector<run> &ru
     }
 
     // canonical numbering: BFS by identity from the source, following edge order
-    std::vector<int32_t> id(B.row.size(), -1), order;
-    order.reserve(B.row.size());
+    std::vector<int32_t> &id = B.id, &order = B.order;
+    id.assign(B.row.size(), -1);
     id[source] = 0;
     order.push_back(source);
     size_t n_edges = 0;
     for (size_t h = 0; h < order.size(); h++) {
-        for (const gedge &e : B.out[order[h]]) {
-            if (id[e.child] < 0) { id[e.child] = (int32_t)order.size(); order.push_back(e.child); }
+        for (int32_t i = B.head[order[h]]; i >= 0; i = B.next[i]) {
+            const int32_t child = B.pool[i].child;
+            if (id[child] < 0) { id[child] = (int32_t)order.size(); order.push_back(child); }
             n_edges++;
         }
     }
@@ -265,7 +286,8 @@ void build_graph(int64_t m, int64_t n, int64_t shift, const std::vector<run> &ru
     for (size_t h = 0; h < order.size(); h++) {
         const int32_t u = order[h];
         G.nodes[3 * h] = B.row[u]; G.nodes[3 * h + 1] = B.col[u]; G.nodes[3 * h + 2] = B.length[u];
-        for (const gedge &e : B.out[u]) {
+        for (int32_t i = B.head[u]; i >= 0; i = B.next[i]) {
+            const gedge &e = B.pool[i];
             int64_t *o = &G.edges[6 * ei++];
             o[0] = (int64_t)h; o[1] = id[e.child]; o[2] = e.start; o[3] = e.end; o[4] = e.from; o[5] = e.to;
         }
@@ -614,6 +636,7 @@ static int graph_batch(malcs_batch *b, const int64_t *shift, const int64_t *max_
     const bool trace = getenv("MALCS_TRACE") != nullptr;
     auto worker = [&]() {
         std::vector<run> runs;
+        builder B;
         for (;;) {
             const uint64_t i = next.fetch_add(1);
             if (i >= N) break;
@@ -639,7 +662,7 @@ static int graph_batch(malcs_batch *b, const int64_t *shift, const int64_t *max_
                 if (runs[r].level < 0 || runs[r].level >= llcs) failed.store(1);
             }
             if (failed.load()) continue;
-            build_graph(m, n, sh, runs, runs.empty() ? 0 : llcs, G);
+            build_graph(B, m, n, sh, runs, runs.empty() ? 0 : llcs, G);
             if (trace) { ns_runs += (uint64_t)((tb - ta) * 1e6); ns_build += (uint64_t)((now_ms() - tb) * 1e6); }
         }
     };
