@@ -1,5 +1,6 @@
 // malcs_api.cpp -- the C-ABI of libmalcs (include/malcs.h): contexts, batches, family-1 entry points.
 #include "malcs_internal.hpp"
+#include <mutex>
 #include <cstdarg>
 #include <cstring>
 #include <new>
@@ -30,6 +31,74 @@ int malcs_device_count(int *count)
     return MALCS_OK;
 }
 
+}  // extern "C"
+
+// ---- staged copies ---------------------------------------------------------------------------------
+namespace {
+constexpr size_t STAGE_BYTES = 16u << 20, STAGE_MAX_COPY = 1u << 20;
+std::mutex g_ctx_mutex;
+std::vector<malcs_ctx *> g_ctxs;
+
+malcs_ctx *ctx_of(hipStream_t st)
+{
+    std::lock_guard<std::mutex> lock(g_ctx_mutex);
+    for (malcs_ctx *c : g_ctxs) if (c->stream == st) return c;
+    return nullptr;
+}
+
+hipError_t drain(malcs_ctx *c)
+{
+    const hipError_t e = hipStreamSynchronize(c->stream);
+    if (e == hipSuccess) for (const staged_copy &s : c->staged) memcpy(s.dst, s.src, s.bytes);
+    c->staged.clear();
+    c->stage_used = 0;
+    return e;
+}
+
+char *stage_slot(malcs_ctx *c, size_t bytes, hipError_t &e)
+{
+    const size_t need = (bytes + 255u) & ~(size_t)255u;
+    e = hipSuccess;
+    if (c->stage_used + need > c->stage_cap) { e = drain(c); if (e != hipSuccess) return nullptr; }
+    char *p = c->stage + c->stage_used;
+    c->stage_used += need;
+    return p;
+}
+}  // namespace
+
+hipError_t malcs_h2d(hipStream_t st, void *dst, const void *src, size_t bytes)
+{
+    if (!bytes) return hipSuccess;
+    malcs_ctx *c = bytes <= STAGE_MAX_COPY ? ctx_of(st) : nullptr;
+    if (!c || !c->stage) return hipMemcpyAsync(dst, src, bytes, hipMemcpyHostToDevice, st);
+    hipError_t e;
+    char *slot = stage_slot(c, bytes, e);
+    if (!slot) return e;
+    memcpy(slot, src, bytes);
+    return hipMemcpyAsync(dst, slot, bytes, hipMemcpyHostToDevice, st);
+}
+
+hipError_t malcs_d2h(hipStream_t st, void *dst, const void *src, size_t bytes)
+{
+    if (!bytes) return hipSuccess;
+    malcs_ctx *c = bytes <= STAGE_MAX_COPY ? ctx_of(st) : nullptr;
+    if (!c || !c->stage) return hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToHost, st);
+    hipError_t e;
+    char *slot = stage_slot(c, bytes, e);
+    if (!slot) return e;
+    e = hipMemcpyAsync(slot, src, bytes, hipMemcpyDeviceToHost, st);
+    if (e == hipSuccess) c->staged.push_back({dst, slot, bytes});
+    return e;
+}
+
+hipError_t malcs_sync(hipStream_t st)
+{
+    malcs_ctx *c = ctx_of(st);
+    return c ? drain(c) : hipStreamSynchronize(st);
+}
+
+extern "C" {
+
 int malcs_ctx_create(int device, malcs_ctx **out)
 {
     if (!out) { malcs_set_error("ctx is NULL"); return MALCS_ERR_ARG; }
@@ -56,6 +125,12 @@ int malcs_ctx_create(int device, malcs_ctx **out)
     MALCS_HIP(hipEventCreate(&c->ev0));
     MALCS_HIP(hipEventCreate(&c->ev1));
     MALCS_HIP(hipEventCreate(&c->ev2));
+    if (hipHostMalloc((void **)&c->stage, STAGE_BYTES, hipHostMallocDefault) == hipSuccess) c->stage_cap = STAGE_BYTES;
+    else { c->stage = nullptr; (void)hipGetLastError(); }        // no staging: copies go straight from pageable memory
+    {
+        std::lock_guard<std::mutex> lock(g_ctx_mutex);
+        g_ctxs.push_back(c);
+    }
     *out = c;
     return MALCS_OK;
 }
@@ -64,7 +139,12 @@ int malcs_ctx_destroy(malcs_ctx *c)
 {
     if (!c) return MALCS_OK;
     hipSetDevice(c->device);
-    if (c->stream) hipStreamSynchronize(c->stream);
+    if (c->stream) malcs_sync(c->stream);
+    {
+        std::lock_guard<std::mutex> lock(g_ctx_mutex);
+        for (size_t i = 0; i < g_ctxs.size(); i++) if (g_ctxs[i] == c) { g_ctxs.erase(g_ctxs.begin() + (std::ptrdiff_t)i); break; }
+    }
+    if (c->stage) hipHostFree(c->stage);
     if (c->ev0) hipEventDestroy(c->ev0);
     if (c->ev1) hipEventDestroy(c->ev1);
     if (c->ev2) hipEventDestroy(c->ev2);
@@ -77,7 +157,7 @@ int malcs_ctx_sync(malcs_ctx *c)
 {
     if (!c) { malcs_set_error("ctx is NULL"); return MALCS_ERR_ARG; }
     MALCS_HIP(hipSetDevice(c->device));
-    MALCS_HIP(hipStreamSynchronize(c->stream));
+    MALCS_HIP(malcs_sync(c->stream));
     return MALCS_OK;
 }
 
@@ -163,21 +243,21 @@ static int batch_build(malcs_ctx *ctx, const uint8_t *syms, uint64_t n_syms,
         MALCS_HIP(hipMalloc(&b->d_a_off, n_pairs * 4)); MALCS_HIP(hipMalloc(&b->d_a_len, n_pairs * 4));
         MALCS_HIP(hipMalloc(&b->d_b_off, n_pairs * 4)); MALCS_HIP(hipMalloc(&b->d_b_len, n_pairs * 4));
         MALCS_HIP(hipMalloc(&b->d_dist, n_pairs * 4));
-        MALCS_HIP(hipMemcpyAsync(b->d_a_off, b->a_off.data(), n_pairs * 4, hipMemcpyHostToDevice, st));
-        MALCS_HIP(hipMemcpyAsync(b->d_a_len, b->a_len.data(), n_pairs * 4, hipMemcpyHostToDevice, st));
-        MALCS_HIP(hipMemcpyAsync(b->d_b_off, b->b_off.data(), n_pairs * 4, hipMemcpyHostToDevice, st));
-        MALCS_HIP(hipMemcpyAsync(b->d_b_len, b->b_len.data(), n_pairs * 4, hipMemcpyHostToDevice, st));
+        MALCS_HIP(malcs_h2d(st, b->d_a_off, b->a_off.data(), n_pairs * 4));
+        MALCS_HIP(malcs_h2d(st, b->d_a_len, b->a_len.data(), n_pairs * 4));
+        MALCS_HIP(malcs_h2d(st, b->d_b_off, b->b_off.data(), n_pairs * 4));
+        MALCS_HIP(malcs_h2d(st, b->d_b_len, b->b_len.data(), n_pairs * 4));
         if (total_blocks) {
             MALCS_HIP(hipMalloc(&d_syms, n_syms ? n_syms : 1));
             MALCS_HIP(hipMalloc(&d_sbo, (size_t)n_seqs * 8)); MALCS_HIP(hipMalloc(&d_sl, (size_t)n_seqs * 4)); MALCS_HIP(hipMalloc(&d_sko, (size_t)n_seqs * 4));
-            MALCS_HIP(hipMemcpyAsync(d_syms, syms, n_syms, hipMemcpyHostToDevice, st));
-            MALCS_HIP(hipMemcpyAsync(d_sbo, seq_byte_off.data(), (size_t)n_seqs * 8, hipMemcpyHostToDevice, st));
-            MALCS_HIP(hipMemcpyAsync(d_sl, seq_len.data(), (size_t)n_seqs * 4, hipMemcpyHostToDevice, st));
-            MALCS_HIP(hipMemcpyAsync(d_sko, seq_blk_off.data(), (size_t)n_seqs * 4, hipMemcpyHostToDevice, st));
+            MALCS_HIP(malcs_h2d(st, d_syms, syms, n_syms));
+            MALCS_HIP(malcs_h2d(st, d_sbo, seq_byte_off.data(), (size_t)n_seqs * 8));
+            MALCS_HIP(malcs_h2d(st, d_sl, seq_len.data(), (size_t)n_seqs * 4));
+            MALCS_HIP(malcs_h2d(st, d_sko, seq_blk_off.data(), (size_t)n_seqs * 4));
             int rc = malcs_pack_launch(ctx, d_syms, d_sbo, d_sl, d_sko, n_seqs, (uint32_t)total_blocks, b->n_planes, b->d_planes);
             if (rc) return rc;
         }
-        MALCS_HIP(hipStreamSynchronize(st));
+        MALCS_HIP(malcs_sync(st));
         hipFree(d_syms); hipFree(d_sbo); hipFree(d_sl); hipFree(d_sko);
     }
     return malcs_dist_plan(b);
@@ -206,7 +286,7 @@ int malcs_batch_destroy(malcs_batch *b)
 {
     if (!b) return MALCS_OK;
     hipSetDevice(b->ctx->device);
-    hipStreamSynchronize(b->ctx->stream);
+    malcs_sync(b->ctx->stream);
     batch_release(b);
     return MALCS_OK;
 }
@@ -225,8 +305,8 @@ int malcs_edit_distance_fetch(malcs_batch *b, int32_t *dist)
     if (!b || (!dist && b->n_pairs)) { malcs_set_error("NULL argument"); return MALCS_ERR_ARG; }
     MALCS_HIP(hipSetDevice(b->ctx->device));
     if (b->n_pairs)
-        MALCS_HIP(hipMemcpyAsync(dist, b->d_dist, b->n_pairs * sizeof(int32_t), hipMemcpyDeviceToHost, b->ctx->stream));
-    MALCS_HIP(hipStreamSynchronize(b->ctx->stream));
+        MALCS_HIP(malcs_d2h(b->ctx->stream, dist, b->d_dist, b->n_pairs * sizeof(int32_t)));
+    MALCS_HIP(malcs_sync(b->ctx->stream));
     return MALCS_OK;
 }
 

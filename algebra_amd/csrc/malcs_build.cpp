@@ -440,8 +440,8 @@ static int graph_batch(malcs_batch *b, const int64_t *shift, const int64_t *max_
     if (N) {
         int rc = malcs_dist_launch(b);
         if (rc) return rc;
-        MALCS_HIP(hipMemcpyAsync(dist.data(), b->d_dist, N * 4ull, hipMemcpyDeviceToHost, st));
-        MALCS_HIP(hipStreamSynchronize(st));
+        MALCS_HIP(malcs_d2h(st, dist.data(), b->d_dist, N * 4ull));
+        MALCS_HIP(malcs_sync(st));
     }
 
     // launch classes.  Short windows keep all their row groups resident (L lanes per pair, several pairs per
@@ -551,20 +551,20 @@ static int graph_batch(malcs_batch *b, const int64_t *shift, const int64_t *max_
                 malcs_set_error("device allocation failed (chunk of %u pairs, %llu MiB of tie-bit rows)", cnt, (unsigned long long)(used >> 18));
                 return MALCS_ERR_NOMEM;
             }
-            MALCS_HIP(hipMemcpyAsync(d_work.p, work.data(), cnt * 4ull, hipMemcpyHostToDevice, st));
-            MALCS_HIP(hipMemcpyAsync(d_scoff.p, sc_off.data(), cnt * 8ull, hipMemcpyHostToDevice, st));
-            MALCS_HIP(hipMemcpyAsync(d_kmin.p, kmin.data(), cnt * 4ull, hipMemcpyHostToDevice, st));
-            MALCS_HIP(hipMemcpyAsync(d_kmax.p, kmax.data(), cnt * 4ull, hipMemcpyHostToDevice, st));
-            MALCS_HIP(hipMemcpyAsync(d_rw.p, rw.data(), cnt * 4ull, hipMemcpyHostToDevice, st));
-            MALCS_HIP(hipMemcpyAsync(d_llcs.p, llcs.data(), cnt * 4ull, hipMemcpyHostToDevice, st));
+            MALCS_HIP(malcs_h2d(st, d_work.p, work.data(), cnt * 4ull));
+            MALCS_HIP(malcs_h2d(st, d_scoff.p, sc_off.data(), cnt * 8ull));
+            MALCS_HIP(malcs_h2d(st, d_kmin.p, kmin.data(), cnt * 4ull));
+            MALCS_HIP(malcs_h2d(st, d_kmax.p, kmax.data(), cnt * 4ull));
+            MALCS_HIP(malcs_h2d(st, d_rw.p, rw.data(), cnt * 4ull));
+            MALCS_HIP(malcs_h2d(st, d_llcs.p, llcs.data(), cnt * 4ull));
             MALCS_HIP(hipEventRecord(ctx->ev0, st));
             int rc = malcs_graph_launch_forward(b, lc.W, lc.logL, lc.band, d_work.p, cnt, d_scratch.p, d_scoff.p,
                                                 d_kmin.p, d_kmax.p, d_rw.p, d_fdist.p);
             if (rc) return rc;
             MALCS_HIP(hipEventRecord(ctx->ev1, st));
             std::vector<int32_t> fdist(cnt);
-            MALCS_HIP(hipMemcpyAsync(fdist.data(), d_fdist.p, cnt * 4ull, hipMemcpyDeviceToHost, st));
-            MALCS_HIP(hipStreamSynchronize(st));
+            MALCS_HIP(malcs_d2h(st, fdist.data(), d_fdist.p, cnt * 4ull));
+            MALCS_HIP(malcs_sync(st));
             float ms = 0;
             MALCS_HIP(hipEventElapsedTime(&ms, ctx->ev0, ctx->ev1));
             ms_fwd += ms;
@@ -586,9 +586,9 @@ static int graph_batch(malcs_batch *b, const int64_t *shift, const int64_t *max_
             }
             for (int attempt = 0;; attempt++) {
                 if (d_events.alloc(ev_total)) { malcs_set_error("device allocation failed (%llu events)", (unsigned long long)ev_total); return MALCS_ERR_NOMEM; }
-                MALCS_HIP(hipMemcpyAsync(d_skip.p, skip.data(), cnt, hipMemcpyHostToDevice, st));
-                MALCS_HIP(hipMemcpyAsync(d_evcap.p, ev_cap.data(), cnt * 4ull, hipMemcpyHostToDevice, st));
-                MALCS_HIP(hipMemcpyAsync(d_evoff.p, ev_off.data(), cnt * 8ull, hipMemcpyHostToDevice, st));
+                MALCS_HIP(malcs_h2d(st, d_skip.p, skip.data(), cnt));
+                MALCS_HIP(malcs_h2d(st, d_evcap.p, ev_cap.data(), cnt * 4ull));
+                MALCS_HIP(malcs_h2d(st, d_evoff.p, ev_off.data(), cnt * 8ull));
                 MALCS_HIP(hipMemsetAsync(d_evcnt.p, 0, cnt * 4ull, st));
                 MALCS_HIP(hipEventRecord(ctx->ev1, st));
                 rc = malcs_graph_launch_reach(b, lc.W, lc.logL, lc.band, d_work.p, cnt, d_scratch.p, d_scoff.p, d_kmin.p,
@@ -596,8 +596,8 @@ static int graph_batch(malcs_batch *b, const int64_t *shift, const int64_t *max_
                 if (rc) return rc;
                 MALCS_HIP(hipEventRecord(ctx->ev2, st));
                 std::vector<uint32_t> ev_cnt(cnt);
-                MALCS_HIP(hipMemcpyAsync(ev_cnt.data(), d_evcnt.p, cnt * 4ull, hipMemcpyDeviceToHost, st));
-                MALCS_HIP(hipStreamSynchronize(st));
+                MALCS_HIP(malcs_d2h(st, ev_cnt.data(), d_evcnt.p, cnt * 4ull));
+                MALCS_HIP(malcs_sync(st));
                 MALCS_HIP(hipEventElapsedTime(&ms, ctx->ev1, ctx->ev2));
                 ms_reach += ms;
                 bool overflow = false;
@@ -613,13 +613,13 @@ static int graph_batch(malcs_batch *b, const int64_t *shift, const int64_t *max_
                 uint64_t packed = 0;
                 for (uint32_t s = 0; s < cnt; s++) { out_off[s] = packed; packed += ev_cnt[s]; }
                 if (d_packed.alloc(packed)) { malcs_set_error("device allocation failed (%llu packed events)", (unsigned long long)packed); return MALCS_ERR_NOMEM; }
-                MALCS_HIP(hipMemcpyAsync(d_outoff.p, out_off.data(), cnt * 8ull, hipMemcpyHostToDevice, st));
+                MALCS_HIP(malcs_h2d(st, d_outoff.p, out_off.data(), cnt * 8ull));
                 rc = malcs_graph_launch_compact(ctx, d_events.p, d_evoff.p, d_evcnt.p, d_outoff.p, cnt, d_packed.p);
                 if (rc) return rc;
                 event_store.emplace_back(packed);
                 std::vector<event> &host_ev = event_store.back();
-                if (packed) MALCS_HIP(hipMemcpyAsync(host_ev.data(), d_packed.p, packed * sizeof(event), hipMemcpyDeviceToHost, st));
-                MALCS_HIP(hipStreamSynchronize(st));
+                if (packed) MALCS_HIP(malcs_d2h(st, host_ev.data(), d_packed.p, packed * sizeof(event)));
+                MALCS_HIP(malcs_sync(st));
                 for (uint32_t s = 0; s < cnt; s++) { pair_events[work[s]].p = host_ev.data() + out_off[s]; pair_events[work[s]].n = ev_cnt[s]; }
                 break;
             }
@@ -695,8 +695,8 @@ static int nodes_batch(malcs_batch *b, const int64_t *shift, const int64_t *max_
     if (N) {
         int rc = malcs_dist_launch(b);
         if (rc) return rc;
-        MALCS_HIP(hipMemcpyAsync(dist.data(), b->d_dist, N * 4ull, hipMemcpyDeviceToHost, st));
-        MALCS_HIP(hipStreamSynchronize(st));
+        MALCS_HIP(malcs_d2h(st, dist.data(), b->d_dist, N * 4ull));
+        MALCS_HIP(malcs_sync(st));
     }
     std::vector<uint32_t> work;
     for (uint64_t i = 0; i < N; i++) {

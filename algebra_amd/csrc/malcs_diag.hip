@@ -460,13 +460,13 @@ int malcs_diag_plan(malcs_batch *b, int nlw, const std::vector<uint32_t> &pairs,
     MALCS_HIP(hipMalloc(&d.d_retry_count, 2 * ncls * sizeof(uint32_t)));   // two sets, used by alternate launches
     MALCS_HIP(hipMalloc(&d_tile_pid, tile_pid.size() * sizeof(uint32_t)));
     MALCS_HIP(hipMalloc(&d_tile_kc, tile_kc.size() * sizeof(uint32_t)));
-    MALCS_HIP(hipMemcpyAsync(d.d_tile_off, tile_off.data(), (n_tiles + 1) * sizeof(uint32_t), hipMemcpyHostToDevice, st));
-    MALCS_HIP(hipMemcpyAsync(d.d_tile_iters, tile_iters.data(), n_tiles * sizeof(uint32_t), hipMemcpyHostToDevice, st));
-    MALCS_HIP(hipMemcpyAsync(d_tile_pid, tile_pid.data(), tile_pid.size() * sizeof(uint32_t), hipMemcpyHostToDevice, st));
-    MALCS_HIP(hipMemcpyAsync(d_tile_kc, tile_kc.data(), tile_kc.size() * sizeof(uint32_t), hipMemcpyHostToDevice, st));
+    MALCS_HIP(malcs_h2d(st, d.d_tile_off, tile_off.data(), (n_tiles + 1) * sizeof(uint32_t)));
+    MALCS_HIP(malcs_h2d(st, d.d_tile_iters, tile_iters.data(), n_tiles * sizeof(uint32_t)));
+    MALCS_HIP(malcs_h2d(st, d_tile_pid, tile_pid.data(), tile_pid.size() * sizeof(uint32_t)));
+    MALCS_HIP(malcs_h2d(st, d_tile_kc, tile_kc.data(), tile_kc.size() * sizeof(uint32_t)));
     if (!classes.empty()) {
-        MALCS_HIP(hipMemcpyAsync(d.d_retry_first, first.data(), classes.size() * sizeof(uint32_t), hipMemcpyHostToDevice, st));
-        MALCS_HIP(hipMemcpyAsync(d.d_retry_cap, cap.data(), classes.size() * sizeof(uint32_t), hipMemcpyHostToDevice, st));
+        MALCS_HIP(malcs_h2d(st, d.d_retry_first, first.data(), classes.size() * sizeof(uint32_t)));
+        MALCS_HIP(malcs_h2d(st, d.d_retry_cap, cap.data(), classes.size() * sizeof(uint32_t)));
     }
     MALCS_HIP(hipMemsetAsync(d.d_retry_count, 0, 2 * ncls * sizeof(uint32_t), st));
     const dim3 grid(max_rows, n_tiles), block(64);
@@ -476,7 +476,7 @@ int malcs_diag_plan(malcs_batch *b, int nlw, const std::vector<uint32_t> &pairs,
     case 4: hipLaunchKernelGGL(k_diag_layout<4>, grid, block, 0, st, b->d_planes, b->d_a_off, b->d_a_len, b->d_b_off, b->d_b_len, d_tile_pid, d_tile_kc, d.d_tile_off, d.d_tile_iters, nlw, d.d_rows); break;
     }
     MALCS_HIP(hipGetLastError());
-    MALCS_HIP(hipStreamSynchronize(st));           // the host vectors above are locals
+    MALCS_HIP(malcs_sync(st));           // the host vectors above are locals
     hipFree(d_tile_pid); hipFree(d_tile_kc);
     d.nlw = nlw; d.T = T; d.n_tiles = n_tiles; d.n_pairs = (uint32_t)pairs.size(); d.window_cells = cells;
     return MALCS_OK;

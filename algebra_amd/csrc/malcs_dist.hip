@@ -440,8 +440,8 @@ int malcs_dist_plan(malcs_batch *b)
     }
     if (n) {
         MALCS_HIP(hipMalloc(&b->d_order, n * sizeof(uint32_t)));
-        MALCS_HIP(hipMemcpyAsync(b->d_order, order.data(), n * sizeof(uint32_t), hipMemcpyHostToDevice, b->ctx->stream));
-        MALCS_HIP(hipStreamSynchronize(b->ctx->stream));   // `order` is a local
+        MALCS_HIP(malcs_h2d(b->ctx->stream, b->d_order, order.data(), n * sizeof(uint32_t)));
+        MALCS_HIP(malcs_sync(b->ctx->stream));   // `order` is a local
     }
     return MALCS_OK;
 }
@@ -541,12 +541,12 @@ int malcs_dist_band(malcs_batch *b, const std::vector<uint32_t> &pairs, int32_t 
             }
             if (!fn) { rc = MALCS_ERR_INTERNAL; malcs_set_error("no band kernel for W=%d planes=%d", W, b->n_planes); break; }
             std::vector<int32_t> got(work.size());
-            hipMemcpyAsync(d_work, work.data(), work.size() * 4, hipMemcpyHostToDevice, st);
-            hipMemcpyAsync(d_thresh, thresh.data(), work.size() * 4, hipMemcpyHostToDevice, st);
+            malcs_h2d(st, d_work, work.data(), work.size() * 4);
+            malcs_h2d(st, d_thresh, thresh.data(), work.size() * 4);
             hipLaunchKernelGGL(fn, dim3((uint32_t)work.size()), dim3(64), 0, st, b->d_planes, b->d_a_off, b->d_a_len,
                                b->d_b_off, b->d_b_len, d_work, d_thresh, d_out);
-            hipMemcpyAsync(got.data(), d_out, work.size() * 4, hipMemcpyDeviceToHost, st);
-            hipError_t e = hipStreamSynchronize(st);
+            malcs_d2h(st, got.data(), d_out, work.size() * 4);
+            hipError_t e = malcs_sync(st);
             if (e != hipSuccess) { rc = MALCS_ERR_HIP; malcs_set_error("band kernel failed: %s", hipGetErrorString(e)); break; }
             for (size_t i = 0; i < work.size(); i++) {
                 if (got[i] <= T) result[slots[i]] = got[i];               // exact: no cheaper alignment can leave the band
@@ -562,10 +562,10 @@ int malcs_dist_band(malcs_batch *b, const std::vector<uint32_t> &pairs, int32_t 
     }
     if (rc == MALCS_OK) {
         for (size_t i = 0; i < pairs.size(); i++) {
-            hipMemcpyAsync(b->d_dist + pairs[i], &result[i], 4, hipMemcpyHostToDevice, st);
+            malcs_h2d(st, b->d_dist + pairs[i], &result[i], 4);
             if (host_out) host_out[i] = result[i];
         }
-        hipStreamSynchronize(st);
+        malcs_sync(st);
     }
     hipFree(d_work); hipFree(d_thresh); hipFree(d_out);
     return rc;

@@ -18,12 +18,27 @@ void malcs_set_error(const char *fmt, ...);
         }                                                                                     \
     } while (0)
 
+// A device-to-host copy that went through the staging buffer: lands in `dst` at the next malcs_sync.
+struct staged_copy { void *dst; const void *src; size_t bytes; };
+
 struct malcs_ctx {
     int device = -1;
     hipStream_t stream = nullptr;
     hipEvent_t ev0 = nullptr, ev1 = nullptr, ev2 = nullptr;
     hipDeviceProp_t prop;
+    // pinned staging for the many small parameter / result copies of a call (a copy from or to pageable memory
+    // costs ~16 us of host time each, from pinned memory it is an enqueue)
+    char *stage = nullptr;
+    size_t stage_cap = 0, stage_used = 0;
+    std::vector<staged_copy> staged;
 };
+
+// Copies on a context's stream and the wait for them.  Small copies are staged through the context's pinned buffer:
+// host-to-device data is captured at the call (the source may be reused at once), device-to-host data reaches its
+// destination when malcs_sync returns -- so results are read after malcs_sync, never after another kind of wait.
+hipError_t malcs_h2d(hipStream_t st, void *dst, const void *src, size_t bytes);
+hipError_t malcs_d2h(hipStream_t st, void *dst, const void *src, size_t bytes);
+hipError_t malcs_sync(hipStream_t st);
 
 // One launch of a family-1 kernel: a class of pairs that share (words per lane, lanes per pair).
 struct dist_bucket {

@@ -149,10 +149,10 @@ int malcs_relmatrix_create(malcs_ctx *ctx, uint64_t n, const int64_t *start, con
         RM_HIP(hipMemsetAsync(h->labels.p, 0, n_cells ? n_cells : 1, st));
         RM_HIP(hipMemsetAsync(d_count.p, 0, 16, st));
         if (n) {
-            RM_HIP(hipMemcpyAsync(d_start.p, start, n * 8, hipMemcpyHostToDevice, st));
-            RM_HIP(hipMemcpyAsync(d_end.p, end, n * 8, hipMemcpyHostToDevice, st));
-            RM_HIP(hipMemcpyAsync(d_key.p, key, n * 4, hipMemcpyHostToDevice, st));
-            RM_HIP(hipMemcpyAsync(d_mask.p, symmask, n * 8, hipMemcpyHostToDevice, st));
+            RM_HIP(malcs_h2d(st, d_start.p, start, n * 8));
+            RM_HIP(malcs_h2d(st, d_end.p, end, n * 8));
+            RM_HIP(malcs_h2d(st, d_key.p, key, n * 4));
+            RM_HIP(malcs_h2d(st, d_mask.p, symmask, n * 8));
         }
         if (h->mine) {
             hipLaunchKernelGGL(k_relation_tiles, dim3(h->mine, (uint32_t)((tile_cells + 255) / 256)), dim3(256), 0, st, h->n, d_start.p,
@@ -160,8 +160,8 @@ int malcs_relmatrix_create(malcs_ctx *ctx, uint64_t n, const int64_t *start, con
             RM_HIP(hipGetLastError());
         }
         unsigned long long count = 0;
-        RM_HIP(hipMemcpyAsync(&count, d_count.p, 8, hipMemcpyDeviceToHost, st));
-        RM_HIP(hipStreamSynchronize(st));
+        RM_HIP(malcs_d2h(st, &count, d_count.p, 8));
+        RM_HIP(malcs_sync(st));
         h->n_pending = count;
         if (count) {
             if (h->cells.alloc(count)) { malcs_set_error("device allocation failed (%llu undecided pairs)", count); rc = MALCS_ERR_NOMEM; break; }
@@ -170,8 +170,8 @@ int malcs_relmatrix_create(malcs_ctx *ctx, uint64_t n, const int64_t *start, con
                                (uint64_t)count, h->cells.p);
             RM_HIP(hipGetLastError());
             h->host_cells.resize(count);
-            RM_HIP(hipMemcpyAsync(h->host_cells.data(), h->cells.p, count * 8, hipMemcpyDeviceToHost, st));
-            RM_HIP(hipStreamSynchronize(st));
+            RM_HIP(malcs_d2h(st, h->host_cells.data(), h->cells.p, count * 8));
+            RM_HIP(malcs_sync(st));
         }
     } while (0);
     if (rc) { delete h; return rc; }
@@ -212,11 +212,11 @@ int malcs_relmatrix_resolve(malcs_relmatrix *h, const uint8_t *codes)
     hipStream_t st = h->ctx->stream;
     dev<uint8_t> d_codes;
     if (d_codes.alloc(h->n_pending)) { malcs_set_error("device allocation failed"); return MALCS_ERR_NOMEM; }
-    MALCS_HIP(hipMemcpyAsync(d_codes.p, codes, h->n_pending, hipMemcpyHostToDevice, st));
+    MALCS_HIP(malcs_h2d(st, d_codes.p, codes, h->n_pending));
     hipLaunchKernelGGL(k_relation_resolve, dim3((uint32_t)((h->n_pending + 255) / 256)), dim3(256), 0, st, h->labels.p, h->cells.p,
                        d_codes.p, h->n_pending);
     MALCS_HIP(hipGetLastError());
-    MALCS_HIP(hipStreamSynchronize(st));
+    MALCS_HIP(malcs_sync(st));
     return MALCS_OK;
 }
 
@@ -225,8 +225,8 @@ int malcs_relmatrix_tiles(const malcs_relmatrix *h, uint8_t *labels)
     if (!h || !labels) { malcs_set_error("NULL argument"); return MALCS_ERR_ARG; }
     MALCS_HIP(hipSetDevice(h->ctx->device));
     const size_t bytes = (size_t)h->per_rank * h->tile * h->tile;
-    if (bytes) MALCS_HIP(hipMemcpyAsync(labels, h->labels.p, bytes, hipMemcpyDeviceToHost, h->ctx->stream));
-    MALCS_HIP(hipStreamSynchronize(h->ctx->stream));
+    if (bytes) MALCS_HIP(malcs_d2h(h->ctx->stream, labels, h->labels.p, bytes));
+    MALCS_HIP(malcs_sync(h->ctx->stream));
     return MALCS_OK;
 }
 
@@ -242,14 +242,14 @@ int malcs_relmatrix_assemble(malcs_relmatrix *h, const uint8_t *gathered, uint8_
     if (d_full.alloc((size_t)h->n * h->n)) { malcs_set_error("device allocation failed (%u x %u labels)", h->n, h->n); return MALCS_ERR_NOMEM; }
     if (gathered) {
         if (d_gathered.alloc(bytes)) { malcs_set_error("device allocation failed (%llu gathered label bytes)", (unsigned long long)bytes); return MALCS_ERR_NOMEM; }
-        MALCS_HIP(hipMemcpyAsync(d_gathered.p, gathered, bytes, hipMemcpyHostToDevice, st));
+        MALCS_HIP(malcs_h2d(st, d_gathered.p, gathered, bytes));
         src = d_gathered.p;
     }
     hipLaunchKernelGGL(k_relation_assemble, dim3(h->n, (h->n + 255u) / 256u), dim3(256), 0, st, h->n, h->tile, h->blocks, h->world,
                        h->per_rank, src, d_full.p);
     MALCS_HIP(hipGetLastError());
-    MALCS_HIP(hipMemcpyAsync(full, d_full.p, (size_t)h->n * h->n, hipMemcpyDeviceToHost, st));
-    MALCS_HIP(hipStreamSynchronize(st));
+    MALCS_HIP(malcs_d2h(st, full, d_full.p, (size_t)h->n * h->n));
+    MALCS_HIP(malcs_sync(st));
     return MALCS_OK;
 }
 

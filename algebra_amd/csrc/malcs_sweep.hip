@@ -477,16 +477,16 @@ int malcs_sweep_runs(malcs_batch *b, const std::vector<uint32_t> &work, const in
             malcs_set_error("device allocation failed (sweep chunk of %u pairs)", cnt);
             return MALCS_ERR_NOMEM;
         }
-        MALCS_HIP(hipMemcpyAsync(d_work.p, work.data() + pos, cnt * 4ull, hipMemcpyHostToDevice, st));
-        MALCS_HIP(hipMemcpyAsync(d_fr_off.p, fr_off.data(), cnt * 8ull, hipMemcpyHostToDevice, st));
+        MALCS_HIP(malcs_h2d(st, d_work.p, work.data() + pos, cnt * 4ull));
+        MALCS_HIP(malcs_h2d(st, d_fr_off.p, fr_off.data(), cnt * 8ull));
         MALCS_HIP(hipMemsetAsync(d_reached.p, 0xff, cnt * 4ull, st));
         int rc = launch_any(b, false, cnt, d_work.p, d_fr.p, d_fr_off.p, d_counts.p, nullptr, nullptr, d_reached.p);
         if (rc) return rc;
         std::vector<uint32_t> counts(cnt);
         std::vector<int32_t> reached(cnt);
-        MALCS_HIP(hipMemcpyAsync(counts.data(), d_counts.p, cnt * 4ull, hipMemcpyDeviceToHost, st));
-        MALCS_HIP(hipMemcpyAsync(reached.data(), d_reached.p, cnt * 4ull, hipMemcpyDeviceToHost, st));
-        MALCS_HIP(hipStreamSynchronize(st));
+        MALCS_HIP(malcs_d2h(st, counts.data(), d_counts.p, cnt * 4ull));
+        MALCS_HIP(malcs_d2h(st, reached.data(), d_reached.p, cnt * 4ull));
+        MALCS_HIP(malcs_sync(st));
         std::vector<uint64_t> off(cnt);
         uint64_t total = 0;
         for (uint32_t s = 0; s < cnt; s++) {
@@ -504,13 +504,13 @@ int malcs_sweep_runs(malcs_batch *b, const std::vector<uint32_t> &work, const in
             return MALCS_ERR_NOMEM;
         }
         if (d_out.alloc(total)) { malcs_set_error("device allocation failed (%llu runs)", (unsigned long long)total); return MALCS_ERR_NOMEM; }
-        MALCS_HIP(hipMemcpyAsync(d_out_off.p, off.data(), cnt * 8ull, hipMemcpyHostToDevice, st));
+        MALCS_HIP(malcs_h2d(st, d_out_off.p, off.data(), cnt * 8ull));
         rc = launch_any(b, true, cnt, d_work.p, d_fr.p, d_fr_off.p, d_counts.p, d_out.p, d_out_off.p, d_reached.p);
         if (rc) return rc;
         const size_t base = out_runs.size();
         out_runs.resize(base + total * 4);
-        if (total) MALCS_HIP(hipMemcpyAsync(out_runs.data() + base, d_out.p, total * 16ull, hipMemcpyDeviceToHost, st));
-        MALCS_HIP(hipStreamSynchronize(st));
+        if (total) MALCS_HIP(malcs_d2h(st, out_runs.data() + base, d_out.p, total * 16ull));
+        MALCS_HIP(malcs_sync(st));
         for (uint32_t s = 0; s < cnt; s++) out_first[pos + s + 1] = base / 4 + off[s] + counts[s];
         pos = end;
     }
@@ -589,13 +589,13 @@ int malcs_sweep_distances(malcs_batch *b, const std::vector<uint32_t> &pairs, in
         malcs_set_error("device allocation failed (sweep over %u pairs)", cnt);
         return MALCS_ERR_NOMEM;
     }
-    MALCS_HIP(hipMemcpyAsync(d_work.p, pairs.data(), cnt * 4ull, hipMemcpyHostToDevice, st));
-    MALCS_HIP(hipMemcpyAsync(d_caps.p, caps.data(), cnt * 4ull, hipMemcpyHostToDevice, st));
-    MALCS_HIP(hipMemcpyAsync(d_fr_off.p, fr_off.data(), cnt * 8ull, hipMemcpyHostToDevice, st));
+    MALCS_HIP(malcs_h2d(st, d_work.p, pairs.data(), cnt * 4ull));
+    MALCS_HIP(malcs_h2d(st, d_caps.p, caps.data(), cnt * 4ull));
+    MALCS_HIP(malcs_h2d(st, d_fr_off.p, fr_off.data(), cnt * 8ull));
     int rc = launch_reach_any(b, false, cnt, d_work.p, d_caps.p, d_fr.p, d_fr_off.p, nullptr, nullptr, d_dist.p);
     if (rc) return rc;
-    MALCS_HIP(hipMemcpyAsync(out.data(), d_dist.p, cnt * 4ull, hipMemcpyDeviceToHost, st));
-    MALCS_HIP(hipStreamSynchronize(st));
+    MALCS_HIP(malcs_d2h(st, out.data(), d_dist.p, cnt * 4ull));
+    MALCS_HIP(malcs_sync(st));
     return MALCS_OK;
 }
 
@@ -643,18 +643,18 @@ int malcs_sweep_optimal_runs(malcs_batch *b, const std::vector<uint32_t> &work, 
             malcs_set_error("device allocation failed (sweep chunk of %u pairs, %llu MiB of reach table)", cnt, (unsigned long long)(tab_total >> 18));
             return MALCS_ERR_NOMEM;
         }
-        MALCS_HIP(hipMemcpyAsync(d_work.p, work.data() + pos, cnt * 4ull, hipMemcpyHostToDevice, st));
-        MALCS_HIP(hipMemcpyAsync(d_dists.p, dists.data(), cnt * 4ull, hipMemcpyHostToDevice, st));
-        MALCS_HIP(hipMemcpyAsync(d_tab_off.p, tab_off.data(), cnt * 8ull, hipMemcpyHostToDevice, st));
-        MALCS_HIP(hipMemcpyAsync(d_fr_off.p, fr_off_b.data(), cnt * 8ull, hipMemcpyHostToDevice, st));
+        MALCS_HIP(malcs_h2d(st, d_work.p, work.data() + pos, cnt * 4ull));
+        MALCS_HIP(malcs_h2d(st, d_dists.p, dists.data(), cnt * 4ull));
+        MALCS_HIP(malcs_h2d(st, d_tab_off.p, tab_off.data(), cnt * 8ull));
+        MALCS_HIP(malcs_h2d(st, d_fr_off.p, fr_off_b.data(), cnt * 8ull));
         MALCS_HIP(hipMemsetAsync(d_tab.p, 0xff, tab_total * 4ull, st));       // an entry never written reaches nothing
         MALCS_HIP(hipEventRecord(ctx->ev0, st));
         int rc = launch_reach_any(b, true, cnt, d_work.p, d_dists.p, d_fr.p, d_fr_off.p, d_tab.p, d_tab_off.p, d_found.p);
         if (rc) return rc;
         MALCS_HIP(hipEventRecord(ctx->ev1, st));
         std::vector<int32_t> found(cnt);
-        MALCS_HIP(hipMemcpyAsync(found.data(), d_found.p, cnt * 4ull, hipMemcpyDeviceToHost, st));
-        MALCS_HIP(hipStreamSynchronize(st));
+        MALCS_HIP(malcs_d2h(st, found.data(), d_found.p, cnt * 4ull));
+        MALCS_HIP(malcs_sync(st));
         float t = 0;
         MALCS_HIP(hipEventElapsedTime(&t, ctx->ev0, ctx->ev1));
         ms[0] += t;
@@ -669,12 +669,12 @@ int malcs_sweep_optimal_runs(malcs_batch *b, const std::vector<uint32_t> &work, 
             cap[s] = 64u + 16u * (uint32_t)dists[s];
             off[s] = total; total += cap[s];
         }
-        MALCS_HIP(hipMemcpyAsync(d_fr_off.p, fr_off_f.data(), cnt * 8ull, hipMemcpyHostToDevice, st));
+        MALCS_HIP(malcs_h2d(st, d_fr_off.p, fr_off_f.data(), cnt * 8ull));
         for (int attempt = 0;; attempt++) {
             if (d_out.p) { hipFree(d_out.p); d_out.p = nullptr; }
             if (d_out.alloc(total)) { malcs_set_error("device allocation failed (%llu runs)", (unsigned long long)total); return MALCS_ERR_NOMEM; }
-            MALCS_HIP(hipMemcpyAsync(d_cap.p, cap.data(), cnt * 4ull, hipMemcpyHostToDevice, st));
-            MALCS_HIP(hipMemcpyAsync(d_out_off.p, off.data(), cnt * 8ull, hipMemcpyHostToDevice, st));
+            MALCS_HIP(malcs_h2d(st, d_cap.p, cap.data(), cnt * 4ull));
+            MALCS_HIP(malcs_h2d(st, d_out_off.p, off.data(), cnt * 8ull));
             MALCS_HIP(hipEventRecord(ctx->ev1, st));
             switch (b->n_planes) {
             case 2: rc = launch_runs<2>(b, cnt, d_work.p, d_dists.p, d_fr.p, d_fr_off.p, d_tab.p, d_tab_off.p, d_out.p, d_out_off.p, d_cap.p, d_cnt.p); break;
@@ -685,8 +685,8 @@ int malcs_sweep_optimal_runs(malcs_batch *b, const std::vector<uint32_t> &work, 
             }
             if (rc) return rc;
             MALCS_HIP(hipEventRecord(ctx->ev2, st));
-            MALCS_HIP(hipMemcpyAsync(got.data(), d_cnt.p, cnt * 4ull, hipMemcpyDeviceToHost, st));
-            MALCS_HIP(hipStreamSynchronize(st));
+            MALCS_HIP(malcs_d2h(st, got.data(), d_cnt.p, cnt * 4ull));
+            MALCS_HIP(malcs_sync(st));
             MALCS_HIP(hipEventElapsedTime(&t, ctx->ev1, ctx->ev2));
             ms[1] += t;
             bool overflow = false;
@@ -701,11 +701,11 @@ int malcs_sweep_optimal_runs(malcs_batch *b, const std::vector<uint32_t> &work, 
         for (uint32_t s = 0; s < cnt; s++) kept += got[s];
         out_runs.resize(base + kept * 4);                                     // once, before any copy lands in it
         for (uint32_t s = 0; s < cnt; s++) {
-            if (got[s]) MALCS_HIP(hipMemcpyAsync(out_runs.data() + base, d_out.p + off[s], (size_t)got[s] * 16ull, hipMemcpyDeviceToHost, st));
+            if (got[s]) MALCS_HIP(malcs_d2h(st, out_runs.data() + base, d_out.p + off[s], (size_t)got[s] * 16ull));
             base += (size_t)got[s] * 4;
             out_first[pos + s + 1] = base >> 2;
         }
-        MALCS_HIP(hipStreamSynchronize(st));
+        MALCS_HIP(malcs_sync(st));
         pos = end;
     }
     return MALCS_OK;
