@@ -189,8 +189,9 @@ def main():
     t0 = time.perf_counter()
     for _ in range(args.steps):
         batch.launch_distances()
-    fence()
+    torch.cuda.synchronize()                       # this rank's K steps are done ...
     elapsed = time.perf_counter() - t0
+    fence()                                        # ... and the job is done when the slowest rank is: MAX below
     if dist is not None:
         t = torch.tensor([elapsed], dtype=torch.float64, device=reduce_device)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
