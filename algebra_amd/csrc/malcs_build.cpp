@@ -32,8 +32,9 @@ int malcs_graph_launch_compact(malcs_ctx *ctx, const void *d_events, const uint6
 int malcs_sweep_runs(malcs_batch *b, const std::vector<uint32_t> &work, const int32_t *dist,
                      std::vector<uint32_t> &out_runs, std::vector<uint64_t> &out_first);
 
-int malcs_sweep_optimal_runs(malcs_batch *b, const std::vector<uint32_t> &work, const int32_t *dist,
+int malcs_sweep_optimal_runs(malcs_batch *b, bool small, const std::vector<uint32_t> &work, const int32_t *dist,
                              std::vector<uint32_t> &out_runs, std::vector<uint64_t> &out_first, float *ms);
+int malcs_sweep_small_dmax();
 
 namespace {
 
@@ -449,8 +450,11 @@ static int graph_batch(malcs_batch *b, const int64_t *shift, const int64_t *max_
     const int band_wmax = malcs_graph_max_band_words(b->n_planes);
     auto band_capacity = [](int W) { const int G = 64 * W; return 61 * (G + 1) - G - 64; };
     std::vector<launch_class> classes;
-    std::vector<uint32_t> sweep_pairs, sweep_flat;
-    std::vector<uint64_t> sweep_first, sweep_slot(N, 0);
+    // [0]: long windows (workgroup of 512), [1]: windows below 4 096 rows at small distance (a wave each)
+    std::vector<uint32_t> sweep_pairs[2], sweep_flat[2];
+    std::vector<uint64_t> sweep_first[2], sweep_slot(N, 0);
+    int64_t small_rows = 192;                           // shorter windows stay with the bit-vector kernels (64 pairs per wave)
+    if (const char *e = getenv("MALCS_SWEEP_MIN_ROWS")) small_rows = atoll(e);
     int64_t sweep_dmax = 32768;                         // beyond: the table (D^2 / 2 words) and the single workgroup stop paying
     if (const char *e = getenv("MALCS_SWEEP_DMAX")) sweep_dmax = atoll(e);
     for (uint64_t i = 0; i < N; i++) {
@@ -463,8 +467,14 @@ static int graph_batch(malcs_batch *b, const int64_t *shift, const int64_t *max_
         int W = 0, logL = 0;
         bool band = false;
         if (m >= 4096u && G.distance <= sweep_dmax) {  // long and similar: the output-sensitive sweeps (malcs_sweep.hip)
-            sweep_pairs.push_back((uint32_t)i);
+            sweep_pairs[0].push_back((uint32_t)i);
             has_runs[i] = 2;
+            continue;
+        }
+        if (m < 4096u && (int64_t)m >= small_rows && G.distance <= std::min<int64_t>(sweep_dmax, malcs_sweep_small_dmax()) &&
+            8 * G.distance <= (int64_t)std::max(m, n)) {   // similar windows: D + 1 steps of a wave instead of n columns
+            sweep_pairs[1].push_back((uint32_t)i);
+            has_runs[i] = 3;
             continue;
         }
         if (m < 4096u) {
@@ -500,12 +510,13 @@ static int graph_batch(malcs_batch *b, const int64_t *shift, const int64_t *max_
     const uint64_t budget_dwords = std::min<uint64_t>(free_b / 2, 64ull << 30) / 4;
 
     float ms_fwd = 0, ms_reach = 0;
-    if (!sweep_pairs.empty()) {
+    for (int shape = 0; shape < 2; shape++) {
+        if (sweep_pairs[shape].empty()) continue;
         float ms[2] = {0, 0};
-        int rc = malcs_sweep_optimal_runs(b, sweep_pairs, dist.data(), sweep_flat, sweep_first, ms);
+        int rc = malcs_sweep_optimal_runs(b, shape == 1, sweep_pairs[shape], dist.data(), sweep_flat[shape], sweep_first[shape], ms);
         if (rc) return rc;
         ms_fwd += ms[0]; ms_reach += ms[1];
-        for (size_t s = 0; s < sweep_pairs.size(); s++) sweep_slot[sweep_pairs[s]] = s;
+        for (size_t s = 0; s < sweep_pairs[shape].size(); s++) sweep_slot[sweep_pairs[shape][s]] = s;
     }
     dev_buf<uint32_t> d_work, d_evcap, d_evcnt, d_scratch;
     dev_buf<uint64_t> d_scoff, d_evoff, d_outoff;
@@ -645,10 +656,12 @@ static int graph_batch(malcs_batch *b, const int64_t *shift, const int64_t *max_
             const int64_t m = b->a_len[i], n = b->b_len[i];
             runs.clear();
             const double ta = trace ? now_ms() : 0;
-            if (has_runs[i] == 2) {                                      // runs straight from the sweep kernels
+            if (has_runs[i] >= 2) {                                      // runs straight from the sweep kernels
                 const uint64_t s = sweep_slot[i];
-                for (uint64_t r = sweep_first[s]; r < sweep_first[s + 1]; r++)
-                    runs.push_back({sweep_flat[4 * r], sweep_flat[4 * r + 1], sweep_flat[4 * r + 2], sweep_flat[4 * r + 3]});
+                const std::vector<uint32_t> &flat = sweep_flat[has_runs[i] - 2];
+                const std::vector<uint64_t> &first = sweep_first[has_runs[i] - 2];
+                for (uint64_t r = first[s]; r < first[s + 1]; r++)
+                    runs.push_back({flat[4 * r], flat[4 * r + 1], flat[4 * r + 2], flat[4 * r + 3]});
                 order_runs(runs, m, n);
             } else if (has_runs[i] && !runs_from_events(pair_events[i], m, n, runs)) { failed.store(1); continue; }
             const double tb = trace ? now_ms() : 0;
@@ -669,7 +682,7 @@ static int graph_batch(malcs_batch *b, const int64_t *shift, const int64_t *max_
     unsigned nt = std::min<unsigned>(16u, std::max(1u, std::thread::hardware_concurrency()));
     {
         // threads pay from a few thousand runs on (a 10 kb tandem-repeat window alone builds 400 000 edges)
-        uint64_t load = sweep_flat.size() / 4;
+        uint64_t load = (sweep_flat[0].size() + sweep_flat[1].size()) / 4;
         for (uint64_t i = 0; i < N; i++) load += pair_events[i].n / 2;
         if (N < 64 && load < 4096) nt = 1;
         nt = (unsigned)std::min<uint64_t>(nt, std::max<uint64_t>(N, 1));

@@ -22,6 +22,9 @@
 #include "malcs_internal.hpp"
 #include <algorithm>
 
+int malcs_graph_launch_compact(malcs_ctx *ctx, const void *d_events, const uint64_t *d_ev_off, const uint32_t *d_ev_n,
+                               const uint64_t *d_out_off, uint32_t count, void *d_out);
+
 namespace {
 
 constexpr int LDS_DIAGS = 8192;
@@ -137,7 +140,9 @@ k_lcs_sweep(const uint32_t *__restrict__ planes, const uint32_t *__restrict__ a_
 //                            iff the sink reaches it with D - d, i.e. iff its row >= m - FRrev_{D-d}[delta - k].
 //                            Emits the maximal match runs that end in such a corner = exactly the runs the
 //                            reach kernel of malcs_graph.hip extracts (level = (row_end + col_end - d)/2 - 1).
-constexpr int SWEEP_THREADS = 512;
+// Two shapes of workgroup: long or divergent pairs get 512 threads and 8 192 diagonals in LDS, windows below 4 096
+// rows at distance <= SMALL_DMAX one wave and 1 024 diagonals -- 5 KB of LDS, so that dozens of pairs share a CU.
+constexpr int BIG_THREADS = 512, BIG_DIAGS = 8192, SMALL_THREADS = 64, SMALL_DIAGS = 1024, SMALL_DMAX = 510;
 constexpr int LOCAL_WORDS = 2;
 constexpr int SWEEP_UNROLL = 4;
 constexpr int32_t NO_STOP = 0x7fffffff;
@@ -168,15 +173,15 @@ __device__ __forceinline__ uint32_t cells32(const uint32_t *__restrict__ A, uint
     return REV ? __brev(mism) : mism;
 }
 
-struct sweep_queue {
+template <int TH> struct sweep_queue {
     int32_t n;
-    int32_t pos[SWEEP_THREADS * SWEEP_UNROLL], k[SWEEP_THREADS * SWEEP_UNROLL], stop[SWEEP_THREADS * SWEEP_UNROLL];
+    int32_t pos[TH * SWEEP_UNROLL], k[TH * SWEEP_UNROLL], stop[TH * SWEEP_UNROLL];
     int32_t first[3];
 };
 
 // the slides the lanes could not finish, one after the other, all threads on each
-template <int NP, bool REV>
-__device__ __forceinline__ void finish_slides(sweep_queue &q, const uint32_t *A, uint32_t na, int32_t m, const uint32_t *B,
+template <int NP, bool REV, int TH>
+__device__ __forceinline__ void finish_slides(sweep_queue<TH> &q, const uint32_t *A, uint32_t na, int32_t m, const uint32_t *B,
                                               uint32_t nb, int32_t n)
 {
     const int32_t nq = q.n;
@@ -200,29 +205,29 @@ __device__ __forceinline__ void finish_slides(sweep_queue &q, const uint32_t *A,
             __syncthreads();
             const int32_t f = q.first[round % 3u];
             if (f != NO_STOP) { if (threadIdx.x == 0) q.stop[i] = f; break; }
-            pos += 32 * SWEEP_THREADS;
+            pos += 32 * TH;
         }
         __syncthreads();                                                      // everyone has read the slot before it is reused
     }
 }
 
-template <int NP, bool REV>
-__global__ void __launch_bounds__(SWEEP_THREADS)
+template <int NP, bool REV, int TH, int DG>
+__global__ void __launch_bounds__(TH)
 k_sweep_reach(const uint32_t *__restrict__ planes, const uint32_t *__restrict__ a_off, const uint32_t *__restrict__ a_len,
               const uint32_t *__restrict__ b_off, const uint32_t *__restrict__ b_len, const uint32_t *__restrict__ work,
               const int32_t *__restrict__ caps, int32_t *__restrict__ fr_scratch, const uint64_t *__restrict__ fr_off,
               int32_t *__restrict__ tab, const uint64_t *__restrict__ tab_off, int32_t *__restrict__ dist_out)
 {
-    __shared__ int32_t lds_fr[LDS_DIAGS];
-    __shared__ sweep_queue q;
+    __shared__ int32_t lds_fr[DG];
+    __shared__ sweep_queue<TH> q;
     const uint32_t w = blockIdx.x, pid = work[w];
     const int32_t m = (int32_t)a_len[pid], n = (int32_t)b_len[pid], delta = n - m, cap = caps[w];
     const uint32_t *A = planes + a_off[pid], *B = planes + b_off[pid];
     const uint32_t na = ((uint32_t)m + 31u) >> 5, nb = ((uint32_t)n + 31u) >> 5;
     const int32_t ndiag = 2 * cap + 3;                                        // k in [-cap - 1, cap + 1]
-    int32_t *FR = ndiag <= LDS_DIAGS ? lds_fr : fr_scratch + fr_off[w];
+    int32_t *FR = ndiag <= DG ? lds_fr : fr_scratch + fr_off[w];
     int32_t *T = tab ? tab + tab_off[w] : nullptr;
-    for (int32_t i = (int32_t)threadIdx.x; i < ndiag; i += SWEEP_THREADS) {
+    for (int32_t i = (int32_t)threadIdx.x; i < ndiag; i += TH) {
         const int32_t k = i - cap - 1;
         FR[i] = (k < 0 ? -k : 0) - 1;
     }
@@ -236,13 +241,13 @@ k_sweep_reach(const uint32_t *__restrict__ planes, const uint32_t *__restrict__ 
         if ((khi + d) & 1) khi--;
         const int32_t nk = khi >= klo ? (khi - klo) / 2 + 1 : 0;
         // a thread takes SWEEP_UNROLL diagonals of a chunk: their loads are independent and overlap
-        for (int32_t base = 0; base < nk; base += SWEEP_THREADS * SWEEP_UNROLL) {
+        for (int32_t base = 0; base < nk; base += TH * SWEEP_UNROLL) {
             int32_t stop[SWEEP_UNROLL], pos[SWEEP_UNROLL], slot[SWEEP_UNROLL];
             uint32_t mism[SWEEP_UNROLL];
             bool mine[SWEEP_UNROLL], open[SWEEP_UNROLL];
 #pragma unroll
             for (int u = 0; u < SWEEP_UNROLL; u++) {
-                const int32_t i = base + u * SWEEP_THREADS + (int32_t)threadIdx.x;
+                const int32_t i = base + u * TH + (int32_t)threadIdx.x;
                 mine[u] = i < nk;
                 const int32_t k = klo + 2 * (mine[u] ? i : 0), idx = k + cap + 1;
                 const int32_t prev = FR[idx], limit = min(m, n - k);
@@ -253,7 +258,7 @@ k_sweep_reach(const uint32_t *__restrict__ planes, const uint32_t *__restrict__ 
             }
 #pragma unroll
             for (int u = 0; u < SWEEP_UNROLL; u++) {
-                const int32_t i = base + u * SWEEP_THREADS + (int32_t)threadIdx.x;
+                const int32_t i = base + u * TH + (int32_t)threadIdx.x;
                 const int32_t k = klo + 2 * (mine[u] ? i : 0);
                 mism[u] = cells32<NP, REV>(A, na, m, B, nb, n, pos[u], pos[u] + k);
             }
@@ -261,7 +266,7 @@ k_sweep_reach(const uint32_t *__restrict__ planes, const uint32_t *__restrict__ 
 #pragma unroll
             for (int u = 0; u < SWEEP_UNROLL; u++) {
                 if (!open[u]) continue;
-                const int32_t i = base + u * SWEEP_THREADS + (int32_t)threadIdx.x;
+                const int32_t i = base + u * TH + (int32_t)threadIdx.x;
                 const int32_t k = klo + 2 * i, limit = min(m, n - k);
                 uint32_t mm = mism[u];
                 int32_t p = pos[u], st = NO_STOP;
@@ -277,7 +282,7 @@ k_sweep_reach(const uint32_t *__restrict__ planes, const uint32_t *__restrict__ 
                 if (st == NO_STOP) { slot[u] = atomicAdd(&q.n, 1); q.pos[slot[u]] = p; q.k[slot[u]] = k; queued = true; }
             }
             if (__syncthreads_or(queued)) {                                   // rare: somebody's slide goes on
-                finish_slides<NP, REV>(q, A, na, m, B, nb, n);
+                finish_slides<NP, REV, TH>(q, A, na, m, B, nb, n);
                 if (threadIdx.x == 0) q.n = 0;                                // everybody has read it (barriers inside)
                 __syncthreads();
 #pragma unroll
@@ -286,7 +291,7 @@ k_sweep_reach(const uint32_t *__restrict__ planes, const uint32_t *__restrict__ 
 #pragma unroll
             for (int u = 0; u < SWEEP_UNROLL; u++) {
                 if (!mine[u]) continue;
-                const int32_t i = base + u * SWEEP_THREADS + (int32_t)threadIdx.x;
+                const int32_t i = base + u * TH + (int32_t)threadIdx.x;
                 const int32_t k = klo + 2 * i;
                 FR[k + cap + 1] = stop[u];                                    // own parity: nobody else reads it in this step
                 if (T) T[(int64_t)d * (d + 1) / 2 + (k + d) / 2] = stop[u];
@@ -298,8 +303,8 @@ k_sweep_reach(const uint32_t *__restrict__ planes, const uint32_t *__restrict__ 
     if (threadIdx.x == 0) dist_out[w] = found;
 }
 
-template <int NP>
-__global__ void __launch_bounds__(SWEEP_THREADS)
+template <int NP, int TH, int DG>
+__global__ void __launch_bounds__(TH)
 k_sweep_runs(const uint32_t *__restrict__ planes, const uint32_t *__restrict__ a_off, const uint32_t *__restrict__ a_len,
              const uint32_t *__restrict__ b_off, const uint32_t *__restrict__ b_len, const uint32_t *__restrict__ work,
              const int32_t *__restrict__ dists, int32_t *__restrict__ fr_scratch, const uint64_t *__restrict__ fr_off,
@@ -307,19 +312,19 @@ k_sweep_runs(const uint32_t *__restrict__ planes, const uint32_t *__restrict__ a
              uint4 *__restrict__ out, const uint64_t *__restrict__ out_off, const uint32_t *__restrict__ out_cap,
              uint32_t *__restrict__ out_cnt)
 {
-    __shared__ int32_t lds_fr[LDS_DIAGS];
-    __shared__ sweep_queue q;
+    __shared__ int32_t lds_fr[DG];
+    __shared__ sweep_queue<TH> q;
     __shared__ uint32_t lds_cnt;
     const uint32_t w = blockIdx.x, pid = work[w];
     const int32_t m = (int32_t)a_len[pid], n = (int32_t)b_len[pid], delta = n - m, D = dists[w];
     const uint32_t *A = planes + a_off[pid], *B = planes + b_off[pid];
     const uint32_t na = ((uint32_t)m + 31u) >> 5, nb = ((uint32_t)n + 31u) >> 5;
     const int32_t kmin = -((D - delta) / 2), kmax = (D + delta) / 2, ndiag = kmax - kmin + 3;
-    int32_t *FR = ndiag <= LDS_DIAGS ? lds_fr : fr_scratch + fr_off[w];
+    int32_t *FR = ndiag <= DG ? lds_fr : fr_scratch + fr_off[w];
     const int32_t *T = tab + tab_off[w];
     uint4 *dst = out + out_off[w];
     const uint32_t cap = out_cap[w];
-    for (int32_t i = (int32_t)threadIdx.x; i < ndiag; i += SWEEP_THREADS) {
+    for (int32_t i = (int32_t)threadIdx.x; i < ndiag; i += TH) {
         const int32_t k = kmin - 1 + i;
         FR[i] = (k < 0 ? -k : 0) - 1;
     }
@@ -332,7 +337,7 @@ k_sweep_runs(const uint32_t *__restrict__ planes, const uint32_t *__restrict__ a
     for (int32_t d = 0; d <= D; d++) {
         const int32_t klo = max(-d, delta - (D - d)), khi = min(d, delta + (D - d));
         const int32_t nk = khi >= klo ? (khi - klo) / 2 + 1 : 0;
-        for (int32_t base = 0; base < nk; base += SWEEP_THREADS) {
+        for (int32_t base = 0; base < nk; base += TH) {
             const int32_t i = base + (int32_t)threadIdx.x;
             const bool mine = i < nk;
             const int32_t k = klo + 2 * i, idx = k - kmin + 1;
@@ -358,7 +363,7 @@ k_sweep_runs(const uint32_t *__restrict__ planes, const uint32_t *__restrict__ a
                 }
             }
             if (__syncthreads_or(slot >= 0)) {                                // rare: somebody's slide goes on
-                finish_slides<NP, false>(q, A, na, m, B, nb, n);
+                finish_slides<NP, false, TH>(q, A, na, m, B, nb, n);
                 if (threadIdx.x == 0) q.n = 0;                                // everybody has read it (barriers inside)
                 __syncthreads();
                 if (slot >= 0) stop = q.stop[slot];
@@ -520,47 +525,53 @@ int malcs_sweep_runs(malcs_batch *b, const std::vector<uint32_t> &work, const in
 namespace {
 
 template <int NP>
-int launch_reach(malcs_batch *b, bool rev, uint32_t count, const uint32_t *d_work, const int32_t *d_caps, int32_t *d_fr,
+int launch_reach(malcs_batch *b, bool small, bool rev, uint32_t count, const uint32_t *d_work, const int32_t *d_caps, int32_t *d_fr,
                  const uint64_t *d_fr_off, int32_t *d_tab, const uint64_t *d_tab_off, int32_t *d_dist)
 {
-    if (rev) hipLaunchKernelGGL((k_sweep_reach<NP, true>), dim3(count), dim3(SWEEP_THREADS), 0, b->ctx->stream, b->d_planes, b->d_a_off,
-                                b->d_a_len, b->d_b_off, b->d_b_len, d_work, d_caps, d_fr, d_fr_off, d_tab, d_tab_off, d_dist);
-    else hipLaunchKernelGGL((k_sweep_reach<NP, false>), dim3(count), dim3(SWEEP_THREADS), 0, b->ctx->stream, b->d_planes, b->d_a_off,
-                            b->d_a_len, b->d_b_off, b->d_b_len, d_work, d_caps, d_fr, d_fr_off, d_tab, d_tab_off, d_dist);
+#define SWEEP_REACH(REV, TH, DG)                                                                                            \
+    hipLaunchKernelGGL((k_sweep_reach<NP, REV, TH, DG>), dim3(count), dim3(TH), 0, b->ctx->stream, b->d_planes, b->d_a_off, b->d_a_len, \
+                       b->d_b_off, b->d_b_len, d_work, d_caps, d_fr, d_fr_off, d_tab, d_tab_off, d_dist)
+    if (small) { if (rev) SWEEP_REACH(true, SMALL_THREADS, SMALL_DIAGS); else SWEEP_REACH(false, SMALL_THREADS, SMALL_DIAGS); }
+    else       { if (rev) SWEEP_REACH(true, BIG_THREADS, BIG_DIAGS);     else SWEEP_REACH(false, BIG_THREADS, BIG_DIAGS); }
+#undef SWEEP_REACH
     MALCS_HIP(hipGetLastError());
     return MALCS_OK;
 }
 
-int launch_reach_any(malcs_batch *b, bool rev, uint32_t count, const uint32_t *d_work, const int32_t *d_caps, int32_t *d_fr,
+int launch_reach_any(malcs_batch *b, bool small, bool rev, uint32_t count, const uint32_t *d_work, const int32_t *d_caps, int32_t *d_fr,
                      const uint64_t *d_fr_off, int32_t *d_tab, const uint64_t *d_tab_off, int32_t *d_dist)
 {
     switch (b->n_planes) {
-    case 2: return launch_reach<2>(b, rev, count, d_work, d_caps, d_fr, d_fr_off, d_tab, d_tab_off, d_dist);
-    case 3: return launch_reach<3>(b, rev, count, d_work, d_caps, d_fr, d_fr_off, d_tab, d_tab_off, d_dist);
-    case 4: return launch_reach<4>(b, rev, count, d_work, d_caps, d_fr, d_fr_off, d_tab, d_tab_off, d_dist);
-    case 8: return launch_reach<8>(b, rev, count, d_work, d_caps, d_fr, d_fr_off, d_tab, d_tab_off, d_dist);
+    case 2: return launch_reach<2>(b, small, rev, count, d_work, d_caps, d_fr, d_fr_off, d_tab, d_tab_off, d_dist);
+    case 3: return launch_reach<3>(b, small, rev, count, d_work, d_caps, d_fr, d_fr_off, d_tab, d_tab_off, d_dist);
+    case 4: return launch_reach<4>(b, small, rev, count, d_work, d_caps, d_fr, d_fr_off, d_tab, d_tab_off, d_dist);
+    case 8: return launch_reach<8>(b, small, rev, count, d_work, d_caps, d_fr, d_fr_off, d_tab, d_tab_off, d_dist);
     }
     malcs_set_error("unsupported plane count %d", b->n_planes);
     return MALCS_ERR_ARG;
 }
 
 template <int NP>
-int launch_runs(malcs_batch *b, uint32_t count, const uint32_t *d_work, const int32_t *d_dists, int32_t *d_fr, const uint64_t *d_fr_off,
+int launch_runs(malcs_batch *b, bool small, uint32_t count, const uint32_t *d_work, const int32_t *d_dists, int32_t *d_fr, const uint64_t *d_fr_off,
                 const int32_t *d_tab, const uint64_t *d_tab_off, uint4 *d_out, const uint64_t *d_out_off, const uint32_t *d_out_cap,
                 uint32_t *d_out_cnt)
 {
-    hipLaunchKernelGGL((k_sweep_runs<NP>), dim3(count), dim3(SWEEP_THREADS), 0, b->ctx->stream, b->d_planes, b->d_a_off, b->d_a_len,
-                       b->d_b_off, b->d_b_len, d_work, d_dists, d_fr, d_fr_off, d_tab, d_tab_off, d_out, d_out_off, d_out_cap, d_out_cnt);
+    if (small) hipLaunchKernelGGL((k_sweep_runs<NP, SMALL_THREADS, SMALL_DIAGS>), dim3(count), dim3(SMALL_THREADS), 0, b->ctx->stream, b->d_planes,
+                                  b->d_a_off, b->d_a_len, b->d_b_off, b->d_b_len, d_work, d_dists, d_fr, d_fr_off, d_tab, d_tab_off, d_out,
+                                  d_out_off, d_out_cap, d_out_cnt);
+    else hipLaunchKernelGGL((k_sweep_runs<NP, BIG_THREADS, BIG_DIAGS>), dim3(count), dim3(BIG_THREADS), 0, b->ctx->stream, b->d_planes,
+                            b->d_a_off, b->d_a_len, b->d_b_off, b->d_b_len, d_work, d_dists, d_fr, d_fr_off, d_tab, d_tab_off, d_out,
+                            d_out_off, d_out_cap, d_out_cnt);
     MALCS_HIP(hipGetLastError());
     return MALCS_OK;
 }
 
 // scratch for FR: pairs whose diagonals do not fit LDS
-uint64_t fr_layout(const std::vector<int64_t> &ndiag, std::vector<uint64_t> &off)
+uint64_t fr_layout(const std::vector<int64_t> &ndiag, int lds_diags, std::vector<uint64_t> &off)
 {
     uint64_t total = 0;
     off.resize(ndiag.size());
-    for (size_t i = 0; i < ndiag.size(); i++) { off[i] = total; if (ndiag[i] > LDS_DIAGS) total += (uint64_t)ndiag[i]; }
+    for (size_t i = 0; i < ndiag.size(); i++) { off[i] = total; if (ndiag[i] > lds_diags) total += (uint64_t)ndiag[i]; }
     return total;
 }
 
@@ -581,7 +592,7 @@ int malcs_sweep_distances(malcs_batch *b, const std::vector<uint32_t> &pairs, in
         ndiag[i] = 2 * (int64_t)caps[i] + 3;
     }
     std::vector<uint64_t> fr_off;
-    const uint64_t fr_total = fr_layout(ndiag, fr_off);
+    const uint64_t fr_total = fr_layout(ndiag, BIG_DIAGS, fr_off);
     dbuf<uint32_t> d_work;
     dbuf<int32_t> d_caps, d_fr, d_dist;
     dbuf<uint64_t> d_fr_off;
@@ -592,7 +603,7 @@ int malcs_sweep_distances(malcs_batch *b, const std::vector<uint32_t> &pairs, in
     MALCS_HIP(malcs_h2d(st, d_work.p, pairs.data(), cnt * 4ull));
     MALCS_HIP(malcs_h2d(st, d_caps.p, caps.data(), cnt * 4ull));
     MALCS_HIP(malcs_h2d(st, d_fr_off.p, fr_off.data(), cnt * 8ull));
-    int rc = launch_reach_any(b, false, cnt, d_work.p, d_caps.p, d_fr.p, d_fr_off.p, nullptr, nullptr, d_dist.p);
+    int rc = launch_reach_any(b, false, false, cnt, d_work.p, d_caps.p, d_fr.p, d_fr_off.p, nullptr, nullptr, d_dist.p);
     if (rc) return rc;
     MALCS_HIP(malcs_d2h(st, out.data(), d_dist.p, cnt * 4ull));
     MALCS_HIP(malcs_sync(st));
@@ -601,9 +612,10 @@ int malcs_sweep_distances(malcs_batch *b, const std::vector<uint32_t> &pairs, in
 
 // Runs on the minimal alignments of the pairs in `work` (distances known: dist[pid]) by the two sweeps: backward
 // with the reach table, forward with emission.  Output as malcs_sweep_runs.  ms[0] += backward, ms[1] += forward pass.
-int malcs_sweep_optimal_runs(malcs_batch *b, const std::vector<uint32_t> &work, const int32_t *dist,
+int malcs_sweep_optimal_runs(malcs_batch *b, bool small, const std::vector<uint32_t> &work, const int32_t *dist,
                              std::vector<uint32_t> &out_runs, std::vector<uint64_t> &out_first, float *ms)
 {
+    const int lds_diags = small ? SMALL_DIAGS : BIG_DIAGS;
     hipStream_t st = b->ctx->stream;
     malcs_ctx *ctx = b->ctx;
     out_first.assign(work.size() + 1, 0);
@@ -633,7 +645,7 @@ int malcs_sweep_optimal_runs(malcs_batch *b, const std::vector<uint32_t> &work, 
         }
         const uint32_t cnt = (uint32_t)(end - pos);
         std::vector<uint64_t> fr_off_b, fr_off_f;
-        const uint64_t fr_b = fr_layout(nd_back, fr_off_b), fr_f = fr_layout(nd_fwd, fr_off_f);
+        const uint64_t fr_b = fr_layout(nd_back, lds_diags, fr_off_b), fr_f = fr_layout(nd_fwd, lds_diags, fr_off_f);
         dbuf<uint32_t> d_work, d_cap, d_cnt;
         dbuf<int32_t> d_dists, d_fr, d_tab, d_found;
         dbuf<uint64_t> d_fr_off, d_tab_off, d_out_off;
@@ -649,7 +661,7 @@ int malcs_sweep_optimal_runs(malcs_batch *b, const std::vector<uint32_t> &work, 
         MALCS_HIP(malcs_h2d(st, d_fr_off.p, fr_off_b.data(), cnt * 8ull));
         MALCS_HIP(hipMemsetAsync(d_tab.p, 0xff, tab_total * 4ull, st));       // an entry never written reaches nothing
         MALCS_HIP(hipEventRecord(ctx->ev0, st));
-        int rc = launch_reach_any(b, true, cnt, d_work.p, d_dists.p, d_fr.p, d_fr_off.p, d_tab.p, d_tab_off.p, d_found.p);
+        int rc = launch_reach_any(b, small, true, cnt, d_work.p, d_dists.p, d_fr.p, d_fr_off.p, d_tab.p, d_tab_off.p, d_found.p);
         if (rc) return rc;
         MALCS_HIP(hipEventRecord(ctx->ev1, st));
         std::vector<int32_t> found(cnt);
@@ -677,10 +689,10 @@ int malcs_sweep_optimal_runs(malcs_batch *b, const std::vector<uint32_t> &work, 
             MALCS_HIP(malcs_h2d(st, d_out_off.p, off.data(), cnt * 8ull));
             MALCS_HIP(hipEventRecord(ctx->ev1, st));
             switch (b->n_planes) {
-            case 2: rc = launch_runs<2>(b, cnt, d_work.p, d_dists.p, d_fr.p, d_fr_off.p, d_tab.p, d_tab_off.p, d_out.p, d_out_off.p, d_cap.p, d_cnt.p); break;
-            case 3: rc = launch_runs<3>(b, cnt, d_work.p, d_dists.p, d_fr.p, d_fr_off.p, d_tab.p, d_tab_off.p, d_out.p, d_out_off.p, d_cap.p, d_cnt.p); break;
-            case 4: rc = launch_runs<4>(b, cnt, d_work.p, d_dists.p, d_fr.p, d_fr_off.p, d_tab.p, d_tab_off.p, d_out.p, d_out_off.p, d_cap.p, d_cnt.p); break;
-            case 8: rc = launch_runs<8>(b, cnt, d_work.p, d_dists.p, d_fr.p, d_fr_off.p, d_tab.p, d_tab_off.p, d_out.p, d_out_off.p, d_cap.p, d_cnt.p); break;
+            case 2: rc = launch_runs<2>(b, small, cnt, d_work.p, d_dists.p, d_fr.p, d_fr_off.p, d_tab.p, d_tab_off.p, d_out.p, d_out_off.p, d_cap.p, d_cnt.p); break;
+            case 3: rc = launch_runs<3>(b, small, cnt, d_work.p, d_dists.p, d_fr.p, d_fr_off.p, d_tab.p, d_tab_off.p, d_out.p, d_out_off.p, d_cap.p, d_cnt.p); break;
+            case 4: rc = launch_runs<4>(b, small, cnt, d_work.p, d_dists.p, d_fr.p, d_fr_off.p, d_tab.p, d_tab_off.p, d_out.p, d_out_off.p, d_cap.p, d_cnt.p); break;
+            case 8: rc = launch_runs<8>(b, small, cnt, d_work.p, d_dists.p, d_fr.p, d_fr_off.p, d_tab.p, d_tab_off.p, d_out.p, d_out_off.p, d_cap.p, d_cnt.p); break;
             default: malcs_set_error("unsupported plane count %d", b->n_planes); rc = MALCS_ERR_ARG;
             }
             if (rc) return rc;
@@ -696,17 +708,26 @@ int malcs_sweep_optimal_runs(malcs_batch *b, const std::vector<uint32_t> &work, 
             total = 0;                                                        // the counts are exact: size every region to its count, redo
             for (uint32_t s = 0; s < cnt; s++) { cap[s] = std::max(cap[s], got[s]); off[s] = total; total += cap[s]; }
         }
+        // gather the used parts on the device, bring them home in one copy
         size_t base = out_runs.size();
+        std::vector<uint64_t> packed_off(cnt);
         uint64_t kept = 0;
-        for (uint32_t s = 0; s < cnt; s++) kept += got[s];
-        out_runs.resize(base + kept * 4);                                     // once, before any copy lands in it
-        for (uint32_t s = 0; s < cnt; s++) {
-            if (got[s]) MALCS_HIP(malcs_d2h(st, out_runs.data() + base, d_out.p + off[s], (size_t)got[s] * 16ull));
-            base += (size_t)got[s] * 4;
-            out_first[pos + s + 1] = base >> 2;
+        for (uint32_t s = 0; s < cnt; s++) { packed_off[s] = kept; kept += got[s]; }
+        out_runs.resize(base + kept * 4);
+        if (kept) {
+            dbuf<uint4> d_packed;
+            dbuf<uint64_t> d_packed_off;
+            if (d_packed.alloc(kept) || d_packed_off.alloc(cnt)) { malcs_set_error("device allocation failed (%llu runs)", (unsigned long long)kept); return MALCS_ERR_NOMEM; }
+            MALCS_HIP(malcs_h2d(st, d_packed_off.p, packed_off.data(), cnt * 8ull));
+            rc = malcs_graph_launch_compact(ctx, d_out.p, d_out_off.p, d_cnt.p, d_packed_off.p, cnt, d_packed.p);
+            if (rc) return rc;
+            MALCS_HIP(malcs_d2h(st, out_runs.data() + base, d_packed.p, kept * 16ull));
+            MALCS_HIP(malcs_sync(st));
         }
-        MALCS_HIP(malcs_sync(st));
+        for (uint32_t s = 0; s < cnt; s++) out_first[pos + s + 1] = (base >> 2) + packed_off[s] + got[s];
         pos = end;
     }
     return MALCS_OK;
 }
+
+int malcs_sweep_small_dmax() { return SMALL_DMAX; }

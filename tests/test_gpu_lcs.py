@@ -83,6 +83,8 @@ def use_path(monkeypatch, path):
     if path == "band":
         monkeypatch.setenv("MALCS_SWEEP_DMAX", "-1")
         monkeypatch.setenv("MALCS_SWEEP_DCAP", "0")
+    elif path == "sweep-all":                  # also the shortest windows through the one-wave sweeps
+        monkeypatch.setenv("MALCS_SWEEP_MIN_ROWS", "1")
     elif path == "mixed":                      # sweeps give up early: their results and the band kernels' in one batch
         monkeypatch.setenv("MALCS_SWEEP_DMAX", "700")
         monkeypatch.setenv("MALCS_SWEEP_DCAP", "700")
@@ -274,11 +276,14 @@ def test_graph_random_medium(native):
         assert digest(got) == rec["graph_sha256"], rec["name"]
 
 
-def test_graph_arrays_vs_oracle(native):
+@pytest.mark.parametrize("path", ["sweep", "sweep-all", "band"])
+def test_graph_arrays_vs_oracle(native, path, monkeypatch):
     """Straight through the C-ABI (no facade objects): arrays equal the oracle's, runs are a
-    sub-list of the oracle's level lists."""
+    sub-list of the oracle's level lists.  Windows below 4 096 rows: bit-vector kernels ("band" = sweeps off) and
+    one-wave sweeps (by default from 192 rows and distance <= length / 8 on, "sweep-all" from 1 row on)."""
     from oracle import oracle as O
     from algebra_amd.lcs.encoding import encode_pairs
+    use_path(monkeypatch, path)
     rs = np.random.RandomState(77)
     pairs, shifts = [], []
     for _ in range(300):
@@ -286,6 +291,13 @@ def test_graph_arrays_vs_oracle(native):
         a, b = gen.pair_of_kind(rs, kind, int(rs.randint(1, 400)), "ACGT"[:rs.randint(1, 5)])
         pairs.append((a, b))
         shifts.append(int(rs.randint(0, 50)))
+    for m in (191, 192, 193, 1000, 2047, 2048, 4095):
+        a = gen.random_seq(rs, m)
+        for p in (0.0, 0.002, 0.02, 0.06):
+            pairs.append((a, gen.mutate(rs, a, p, p)))
+            shifts.append(0)
+        pairs.append((a, a[m // 3:]))
+        shifts.append(7)
     syms, a_off, a_len, b_off, b_len, n_symbols = encode_pairs(pairs)
     batch = native.Batch(native.default_context(), syms, a_off, a_len, b_off, b_len, n_symbols)
     res = batch.graphs(np.array(shifts, np.int64))
