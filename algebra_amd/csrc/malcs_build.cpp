@@ -42,14 +42,40 @@ struct event { uint32_t row, col, level, kind; };      // kind 0 = run ends in (
 
 struct run { int64_t row, col, len, level; };
 
+// The result arrays of all pairs a worker thread built sit back to back in that thread's blocks (no allocation per
+// pair); a pair holds views.
+struct i64_view {
+    int64_t *p = nullptr;
+    size_t n = 0;
+    size_t size() const { return n; }
+    bool empty() const { return n == 0; }
+    int64_t *data() const { return p; }
+    int64_t &operator[](size_t i) const { return p[i]; }
+};
+
+struct i64_store {
+    std::deque<std::vector<int64_t>> blocks;
+    size_t used = 0;
+    i64_view take(size_t count)
+    {
+        if (blocks.empty() || used + count > blocks.back().size()) {
+            blocks.emplace_back(std::max<size_t>(count, (size_t)1 << 18));
+            used = 0;
+        }
+        i64_view v{blocks.back().data() + used, count};
+        used += count;
+        return v;
+    }
+};
+
 struct pair_graph {
     int32_t status = MALCS_PAIR_OK;
     int64_t distance = 0;
     int64_t n_levels = 0;
     int64_t supremal[4] = {0, 0, 0, 0};
-    std::vector<int64_t> runs;      // 4 per run (shifted row, col; length; level)
-    std::vector<int64_t> nodes;     // 3 per node
-    std::vector<int64_t> edges;     // 6 per edge
+    i64_view runs;                  // 4 per run (shifted row, col; length; level)
+    i64_view nodes;                 // 3 per node
+    i64_view edges;                 // 6 per edge
     std::vector<int64_t> canon;     // 4 per canonical variant (start, end, obs_from, obs_to), filled on demand
     bool canon_done = false;
 };
@@ -153,7 +179,8 @@ struct builder {
     }
 };
 
-void build_graph(builder &B, int64_t m, int64_t n, int64_t shift, const std::vector<run> &runs, int64_t n_levels, pair_graph &G)
+void build_graph(builder &B, i64_store &store, int64_t m, int64_t n, int64_t shift, const std::vector<run> &runs, int64_t n_levels,
+                 pair_graph &G)
 {
     B.clear();
     int32_t source, sink;
@@ -281,8 +308,8 @@ void build_graph(builder &B, int64_t m, int64_t n, int64_t shift, const std::vec
             n_edges++;
         }
     }
-    G.nodes.resize(order.size() * 3);
-    G.edges.resize(n_edges * 6);
+    G.nodes = store.take(order.size() * 3);
+    G.edges = store.take(n_edges * 6);
     size_t ei = 0;
     for (size_t h = 0; h < order.size(); h++) {
         const int32_t u = order[h];
@@ -423,6 +450,7 @@ double now_ms()
 
 struct malcs_graphs {
     std::vector<pair_graph> g;
+    std::deque<i64_store> stores;   // one per worker thread
     float timing[3] = {0, 0, 0};
 };
 
@@ -645,7 +673,8 @@ static int graph_batch(malcs_batch *b, const int64_t *shift, const int64_t *max_
     std::atomic<int> failed(0);
     std::atomic<uint64_t> ns_runs(0), ns_build(0);
     const bool trace = getenv("MALCS_TRACE") != nullptr;
-    auto worker = [&]() {
+    auto worker = [&](i64_store *mine) {
+        i64_store &store = *mine;
         std::vector<run> runs;
         builder B;
         for (;;) {
@@ -668,14 +697,14 @@ static int graph_batch(malcs_batch *b, const int64_t *shift, const int64_t *max_
             const int64_t llcs = (m + n - G.distance) / 2;
             G.n_levels = runs.empty() ? (std::min(m, n) > 0 ? 1 : 0) : llcs;
             const int64_t sh = shift ? shift[i] : 0;
-            G.runs.resize(runs.size() * 4);
+            G.runs = store.take(runs.size() * 4);
             for (size_t r = 0; r < runs.size(); r++) {
                 G.runs[4 * r] = runs[r].row + sh; G.runs[4 * r + 1] = runs[r].col + sh;
                 G.runs[4 * r + 2] = runs[r].len; G.runs[4 * r + 3] = runs[r].level;
                 if (runs[r].level < 0 || runs[r].level >= llcs) failed.store(1);
             }
             if (failed.load()) continue;
-            build_graph(B, m, n, sh, runs, runs.empty() ? 0 : llcs, G);
+            build_graph(B, store, m, n, sh, runs, runs.empty() ? 0 : llcs, G);
             if (trace) { ns_runs += (uint64_t)((tb - ta) * 1e6); ns_build += (uint64_t)((now_ms() - tb) * 1e6); }
         }
     };
@@ -688,8 +717,9 @@ static int graph_batch(malcs_batch *b, const int64_t *shift, const int64_t *max_
         nt = (unsigned)std::min<uint64_t>(nt, std::max<uint64_t>(N, 1));
     }
     std::vector<std::thread> pool;
-    for (unsigned t = 1; t < nt; t++) pool.emplace_back(worker);
-    worker();
+    out->stores.resize(nt);
+    for (unsigned t = 1; t < nt; t++) pool.emplace_back(worker, &out->stores[t]);
+    worker(&out->stores[0]);
     for (std::thread &t : pool) t.join();
     out->timing[2] = (float)(now_ms() - t0);
     if (trace) fprintf(stderr, "malcs host build: %llu pairs, %u threads, wall %.2f ms; summed over threads: events->runs %.2f ms, build_graph %.2f ms\n",
@@ -739,7 +769,8 @@ static int nodes_batch(malcs_batch *b, const int64_t *shift, const int64_t *max_
         }
         order_runs(runs, m, n);
         G.n_levels = top + 1;                                             // lcs_nodes[:max_lcs_pos + 1], :348
-        G.runs.resize(runs.size() * 4);
+        if (out->stores.empty()) out->stores.resize(1);
+        G.runs = out->stores[0].take(runs.size() * 4);
         for (size_t r = 0; r < runs.size(); r++) {
             G.runs[4 * r] = runs[r].row + sh; G.runs[4 * r + 1] = runs[r].col + sh;
             G.runs[4 * r + 2] = runs[r].len; G.runs[4 * r + 3] = runs[r].level;

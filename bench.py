@@ -101,16 +101,30 @@ def extra_configs(ctx, _native, gen):
                                     "GCUPS": round(fc / (ms * 1e-3) / 1e9, 1),
                                     "roofline_frac": round(fc * OPS_PER_CELL / (ms * 1e-3) / PEAK_LANE_OPS, 4)}
     full.close()
-    n = 20000
+    n = 100000
     batch = _native.Batch(ctx, *gen.c2_batch(n, seed=12), 4)
     batch.graphs().close()                                     # warm-up
     t0 = time.perf_counter()
     g = batch.graphs()
     wall = time.perf_counter() - t0
-    out["c2_lcs_graphs"] = {"pairs": n, "graphs_per_s": round(n / wall, 1), "forward_ms": round(float(g.timing[0]), 3),
-                            "reach_ms": round(float(g.timing[1]), 3), "host_build_ms": round(float(g.timing[2]), 1),
-                            "tie_bit_GB_per_s": {"forward_write": round(n * 1e6 * 0.25 / (float(g.timing[0]) * 1e-3) / 1e9, 1),
-                                                 "reach_read": round(n * 1e6 * 0.25 / (float(g.timing[1]) * 1e-3) / 1e9, 1)}}
+    out["c2_lcs_graphs"] = {"pairs": n, "graphs_per_s": round(n / wall, 1), "device_path": "one-wave sweeps (k_sweep_reach + k_sweep_runs)",
+                            "backward_sweep_ms": round(float(g.timing[0]), 3), "forward_sweep_ms": round(float(g.timing[1]), 3),
+                            "host_build_ms": round(float(g.timing[2]), 1)}
+    g.close()
+    batch.close()
+    # the same shape through the bit-vector kernels (what divergent windows use): HBM-bound tie-bit rows
+    n = 20000
+    os.environ["MALCS_SWEEP_DMAX"] = "-1"
+    batch = _native.Batch(ctx, *gen.c2_batch(n, seed=12), 4)
+    batch.graphs().close()
+    t0 = time.perf_counter()
+    g = batch.graphs()
+    wall = time.perf_counter() - t0
+    del os.environ["MALCS_SWEEP_DMAX"]
+    out["c2_lcs_graphs_bitvector"] = {"pairs": n, "graphs_per_s": round(n / wall, 1), "forward_ms": round(float(g.timing[0]), 3),
+                                      "reach_ms": round(float(g.timing[1]), 3), "host_build_ms": round(float(g.timing[2]), 1),
+                                      "tie_bit_GB_per_s": {"forward_write": round(n * 1e6 * 0.25 / (float(g.timing[0]) * 1e-3) / 1e9, 1),
+                                                           "reach_read": round(n * 1e6 * 0.25 / (float(g.timing[1]) * 1e-3) / 1e9, 1)}}
     g.close()
     batch.close()
     from algebra_amd.lcs import LCSgraph
