@@ -220,6 +220,7 @@ k_sweep_reach(const uint32_t *__restrict__ planes, const uint32_t *__restrict__ 
 {
     __shared__ int32_t lds_fr[DG];
     __shared__ sweep_queue<TH> q;
+    constexpr int U = TH >= 256 ? SWEEP_UNROLL : 1;      // a single wave rarely has more diagonals than lanes
     const uint32_t w = blockIdx.x, pid = work[w];
     const int32_t m = (int32_t)a_len[pid], n = (int32_t)b_len[pid], delta = n - m, cap = caps[w];
     const uint32_t *A = planes + a_off[pid], *B = planes + b_off[pid];
@@ -240,13 +241,13 @@ k_sweep_reach(const uint32_t *__restrict__ planes, const uint32_t *__restrict__ 
         if ((klo + d) & 1) klo++;
         if ((khi + d) & 1) khi--;
         const int32_t nk = khi >= klo ? (khi - klo) / 2 + 1 : 0;
-        // a thread takes SWEEP_UNROLL diagonals of a chunk: their loads are independent and overlap
-        for (int32_t base = 0; base < nk; base += TH * SWEEP_UNROLL) {
-            int32_t stop[SWEEP_UNROLL], pos[SWEEP_UNROLL], slot[SWEEP_UNROLL];
-            uint32_t mism[SWEEP_UNROLL];
-            bool mine[SWEEP_UNROLL], open[SWEEP_UNROLL];
+        // a thread takes U diagonals of a chunk: their loads are independent and overlap
+        for (int32_t base = 0; base < nk; base += TH * U) {
+            int32_t stop[U], pos[U], slot[U];
+            uint32_t mism[U];
+            bool mine[U], open[U];
 #pragma unroll
-            for (int u = 0; u < SWEEP_UNROLL; u++) {
+            for (int u = 0; u < U; u++) {
                 const int32_t i = base + u * TH + (int32_t)threadIdx.x;
                 mine[u] = i < nk;
                 const int32_t k = klo + 2 * (mine[u] ? i : 0), idx = k + cap + 1;
@@ -257,14 +258,14 @@ k_sweep_reach(const uint32_t *__restrict__ planes, const uint32_t *__restrict__ 
                 pos[u] = min(max(max(FR[idx - 1], FR[idx + 1] + 1), prev + 1), limit);
             }
 #pragma unroll
-            for (int u = 0; u < SWEEP_UNROLL; u++) {
+            for (int u = 0; u < U; u++) {
                 const int32_t i = base + u * TH + (int32_t)threadIdx.x;
                 const int32_t k = klo + 2 * (mine[u] ? i : 0);
                 mism[u] = cells32<NP, REV>(A, na, m, B, nb, n, pos[u], pos[u] + k);
             }
             bool queued = false;
 #pragma unroll
-            for (int u = 0; u < SWEEP_UNROLL; u++) {
+            for (int u = 0; u < U; u++) {
                 if (!open[u]) continue;
                 const int32_t i = base + u * TH + (int32_t)threadIdx.x;
                 const int32_t k = klo + 2 * i, limit = min(m, n - k);
@@ -286,10 +287,10 @@ k_sweep_reach(const uint32_t *__restrict__ planes, const uint32_t *__restrict__ 
                 if (threadIdx.x == 0) q.n = 0;                                // everybody has read it (barriers inside)
                 __syncthreads();
 #pragma unroll
-                for (int u = 0; u < SWEEP_UNROLL; u++) if (slot[u] >= 0) stop[u] = q.stop[slot[u]];
+                for (int u = 0; u < U; u++) if (slot[u] >= 0) stop[u] = q.stop[slot[u]];
             }
 #pragma unroll
-            for (int u = 0; u < SWEEP_UNROLL; u++) {
+            for (int u = 0; u < U; u++) {
                 if (!mine[u]) continue;
                 const int32_t i = base + u * TH + (int32_t)threadIdx.x;
                 const int32_t k = klo + 2 * i;
@@ -314,6 +315,7 @@ k_sweep_runs(const uint32_t *__restrict__ planes, const uint32_t *__restrict__ a
 {
     __shared__ int32_t lds_fr[DG];
     __shared__ sweep_queue<TH> q;
+    constexpr int U = TH >= 256 ? SWEEP_UNROLL : 1;      // a single wave rarely has more diagonals than lanes
     __shared__ uint32_t lds_cnt;
     const uint32_t w = blockIdx.x, pid = work[w];
     const int32_t m = (int32_t)a_len[pid], n = (int32_t)b_len[pid], delta = n - m, D = dists[w];
@@ -337,75 +339,97 @@ k_sweep_runs(const uint32_t *__restrict__ planes, const uint32_t *__restrict__ a
     for (int32_t d = 0; d <= D; d++) {
         const int32_t klo = max(-d, delta - (D - d)), khi = min(d, delta + (D - d));
         const int32_t nk = khi >= klo ? (khi - klo) / 2 + 1 : 0;
-        for (int32_t base = 0; base < nk; base += TH) {
-            const int32_t i = base + (int32_t)threadIdx.x;
-            const bool mine = i < nk;
-            const int32_t k = klo + 2 * i, idx = k - kmin + 1;
-            int32_t stop = 0, slot = -1, prev = 0, x = 0;
-            bool active = false;
-            if (mine) {
-                prev = FR[idx];
-                const int32_t limit = min(m, n - k);
-                stop = prev;
-                if (prev < limit) {
-                    active = true;
-                    x = min(max(max(FR[idx - 1], FR[idx + 1] + 1), prev + 1), limit);
-                    int32_t pos = x;
-                    stop = NO_STOP;
-#pragma unroll 1
-                    for (int wi = 0; wi < LOCAL_WORDS && stop == NO_STOP; wi++) {
-                        uint32_t mism = cells32<NP, false>(A, na, m, B, nb, n, pos, pos + k);
-                        const int32_t valid = limit - pos;
-                        if (valid < 32) mism |= valid <= 0 ? ~0u : (~0u << valid);
-                        if (mism) stop = pos + (int32_t)__builtin_ctz(mism); else pos += 32;
-                    }
-                    if (stop == NO_STOP) { slot = atomicAdd(&q.n, 1); q.pos[slot] = pos; q.k[slot] = k; }
-                }
+        // as in k_sweep_reach: U diagonals per thread, their loads (FR, table, first words) in flight together
+        for (int32_t base = 0; base < nk; base += TH * U) {
+            int32_t stop[U], slot[U], prev[U], x[U], reach[U];
+            uint32_t first_word[U];
+            bool mine[U], active[U];
+#pragma unroll
+            for (int u = 0; u < U; u++) {
+                const int32_t i = base + u * TH + (int32_t)threadIdx.x;
+                mine[u] = i < nk;
+                const int32_t k = klo + 2 * (mine[u] ? i : 0), idx = k - kmin + 1;
+                const int32_t limit = min(m, n - k), dd = D - d, kk = delta - k;
+                prev[u] = FR[idx];
+                stop[u] = prev[u];
+                slot[u] = -1;
+                active[u] = mine[u] && prev[u] < limit;
+                x[u] = min(max(max(FR[idx - 1], FR[idx + 1] + 1), prev[u] + 1), limit);
+                reach[u] = T[(int64_t)dd * (dd + 1) / 2 + (kk + dd) / 2];         // rows the sink reaches back on this diagonal
             }
-            if (__syncthreads_or(slot >= 0)) {                                // rare: somebody's slide goes on
+#pragma unroll
+            for (int u = 0; u < U; u++) {
+                const int32_t i = base + u * TH + (int32_t)threadIdx.x;
+                const int32_t k = klo + 2 * (mine[u] ? i : 0);
+                first_word[u] = cells32<NP, false>(A, na, m, B, nb, n, x[u], x[u] + k);
+            }
+            bool queued = false;
+#pragma unroll
+            for (int u = 0; u < U; u++) {
+                if (!active[u]) continue;
+                const int32_t i = base + u * TH + (int32_t)threadIdx.x;
+                const int32_t k = klo + 2 * i, limit = min(m, n - k);
+                uint32_t mism = first_word[u];
+                int32_t pos = x[u], st = NO_STOP;
+                for (int wi = 0;; wi++) {
+                    const int32_t valid = limit - pos;
+                    if (valid < 32) mism |= valid <= 0 ? ~0u : (~0u << valid);
+                    if (mism) { st = pos + (int32_t)__builtin_ctz(mism); break; }
+                    pos += 32;
+                    if (wi + 1 == LOCAL_WORDS) break;
+                    mism = cells32<NP, false>(A, na, m, B, nb, n, pos, pos + k);
+                }
+                stop[u] = st;
+                if (st == NO_STOP) { slot[u] = atomicAdd(&q.n, 1); q.pos[slot[u]] = pos; q.k[slot[u]] = k; queued = true; }
+            }
+            if (__syncthreads_or(queued)) {                                   // rare: somebody's slide goes on
                 finish_slides<NP, false, TH>(q, A, na, m, B, nb, n);
                 if (threadIdx.x == 0) q.n = 0;                                // everybody has read it (barriers inside)
                 __syncthreads();
-                if (slot >= 0) stop = q.stop[slot];
+#pragma unroll
+                for (int u = 0; u < U; u++) if (slot[u] >= 0) stop[u] = q.stop[slot[u]];
             }
-            if (mine) FR[idx] = stop;                                         // own parity: nobody else reads it in this step
-            if (active) {
-                const int32_t dd = D - d, kk = delta - k;
-                const int32_t lo = max(prev + 1, m - T[(int64_t)dd * (dd + 1) / 2 + (kk + dd) / 2]);   // first corner the sink reaches
-                if (stop >= lo) {
-                    // start of the run that holds cell s0 - 1 (cells before prev + 1 belong to an earlier budget)
-                    const int32_t s0 = min(lo, x);
-                    int32_t s = s0;
-                    while (s > prev + 1) {
-                        const int32_t ws = s - 32;
-                        uint32_t mism = cells32<NP, false>(A, na, m, B, nb, n, ws, ws + k);
-                        const int32_t before = prev + 1 - ws;
-                        if (before > 0) mism |= before >= 32 ? ~0u : ((1u << before) - 1u);
-                        if (mism) { s = ws + 32 - (int32_t)__builtin_clz(mism); break; }
-                        s = ws;
-                    }
-                    // the cells before x: runs may end there
-                    int32_t pos = s, run_start = s;
-                    uint32_t in_run = 0;
-                    while (pos < x) {
-                        const uint32_t mism = cells32<NP, false>(A, na, m, B, nb, n, pos, pos + k);
-                        const int32_t nbits = min(32, x - pos);
-                        const uint32_t low = nbits == 32 ? ~0u : ((1u << nbits) - 1u);
-                        const uint32_t match = ~mism & low;
-                        uint32_t turn = (match ^ ((match << 1) | in_run)) & low;
-                        while (turn) {
-                            const int32_t t = __builtin_ctz(turn);
-                            turn &= turn - 1u;
-                            if ((match >> t) & 1u) run_start = pos + t;
-                            else if (pos + t >= lo) emit(run_start, pos + t, k, d);
-                        }
-                        in_run = (match >> (nbits - 1)) & 1u;
-                        pos += 32;
-                    }
-                    // from x on everything up to `stop` matches
-                    const int32_t fs = in_run ? run_start : x;
-                    if (stop > fs) emit(fs, stop, k, d);
+#pragma unroll
+            for (int u = 0; u < U; u++) {
+                if (!mine[u]) continue;
+                const int32_t i = base + u * TH + (int32_t)threadIdx.x;
+                const int32_t k = klo + 2 * i;
+                FR[k - kmin + 1] = stop[u];                                   // own parity: nobody else reads it in this step
+                if (!active[u]) continue;
+                const int32_t lo = max(prev[u] + 1, m - reach[u]);            // first corner the sink reaches
+                if (stop[u] < lo) continue;
+                // start of the run that holds cell s0 - 1 (cells before prev + 1 belong to an earlier budget)
+                const int32_t s0 = min(lo, x[u]);
+                int32_t s = s0;
+                while (s > prev[u] + 1) {
+                    const int32_t ws = s - 32;
+                    uint32_t mism = cells32<NP, false>(A, na, m, B, nb, n, ws, ws + k);
+                    const int32_t before = prev[u] + 1 - ws;
+                    if (before > 0) mism |= before >= 32 ? ~0u : ((1u << before) - 1u);
+                    if (mism) { s = ws + 32 - (int32_t)__builtin_clz(mism); break; }
+                    s = ws;
                 }
+                // the cells before x: runs may end there
+                int32_t pos = s, run_start = s;
+                uint32_t in_run = 0;
+                while (pos < x[u]) {
+                    const uint32_t mism = cells32<NP, false>(A, na, m, B, nb, n, pos, pos + k);
+                    const int32_t nbits = min(32, x[u] - pos);
+                    const uint32_t low = nbits == 32 ? ~0u : ((1u << nbits) - 1u);
+                    const uint32_t match = ~mism & low;
+                    uint32_t turn = (match ^ ((match << 1) | in_run)) & low;
+                    while (turn) {
+                        const int32_t t = __builtin_ctz(turn);
+                        turn &= turn - 1u;
+                        if ((match >> t) & 1u) run_start = pos + t;
+                        else if (pos + t >= lo) emit(run_start, pos + t, k, d);
+                    }
+                    in_run = (match >> (nbits - 1)) & 1u;
+                    pos += 32;
+                }
+                // from x on everything up to `stop` matches
+                const int32_t fs = in_run ? run_start : x[u];
+                if (stop[u] > fs) emit(fs, stop[u], k, d);
             }
         }
         __syncthreads();                                                      // budget d + 1 reads what budget d wrote
