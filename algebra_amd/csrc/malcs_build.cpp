@@ -32,7 +32,7 @@ int malcs_graph_launch_compact(malcs_ctx *ctx, const void *d_events, const uint6
 int malcs_sweep_runs(malcs_batch *b, const std::vector<uint32_t> &work, const int32_t *dist,
                      std::vector<uint32_t> &out_runs, std::vector<uint64_t> &out_first);
 
-int malcs_sweep_optimal_runs(malcs_batch *b, bool small, const std::vector<uint32_t> &work, const int32_t *dist,
+int malcs_sweep_optimal_runs(malcs_batch *b, bool small, const std::vector<uint32_t> &work, int32_t *dist, int32_t unknown_cap,
                              std::vector<uint32_t> &out_runs, std::vector<uint64_t> &out_first, float *ms);
 int malcs_sweep_small_dmax();
 
@@ -464,13 +464,56 @@ static int graph_batch(malcs_batch *b, const int64_t *shift, const int64_t *max_
     std::deque<std::vector<event>> event_store;          // one buffer per chunk, alive until the graphs are built
     std::vector<uint8_t> has_runs(N, 0);
 
+    // [0]: long windows (workgroup of 512), [1]: windows below 4 096 rows at small distance (a wave each),
+    // [2], [3]: sequences beyond a resident pattern, whose sweeps also find the distance
+    struct sweep_set { std::vector<uint32_t> pairs, flat; std::vector<uint64_t> first; };
+    sweep_set sweeps[4];
+    std::vector<uint64_t> sweep_slot(N, 0);
+    int64_t sweep_dmax = 32768;                         // beyond: the table (D^2 / 2 words) and the single workgroup stop paying
+    if (const char *e = getenv("MALCS_SWEEP_DMAX")) sweep_dmax = atoll(e);
+    float ms_fwd = 0, ms_reach = 0;
+
     // exact distances first (kernel family 1): they decide max_distance, the band and the event budget
-    std::vector<int32_t> dist(N);
+    std::vector<int32_t> dist(N, -1);
     if (N) {
-        int rc = malcs_dist_launch(b);
+        int rc = malcs_dist_launch_resident(b);
         if (rc) return rc;
         MALCS_HIP(malcs_d2h(st, dist.data(), b->d_dist, N * 4ull));
         MALCS_HIP(malcs_sync(st));
+        // Sequences beyond a resident pattern: the backward sweep finds the distance while it fills its table, first
+        // with room for 1 024 edits, then for sweep_dmax; what is further apart goes to the band kernels.
+        std::vector<uint32_t> todo;
+        for (uint32_t pid : b->band_pairs) {
+            dist[pid] = -1;
+            const int64_t md = max_distance ? max_distance[pid] : 0;
+            if (b->a_len[pid] >= 4096u && !md) todo.push_back(pid); // with a max_distance the verdict may come before any graph
+        }
+        const int64_t caps[2] = {std::min<int64_t>(1024, sweep_dmax), sweep_dmax};
+        for (int stage = 0; stage < 2 && !todo.empty() && caps[stage] > 0; stage++) {
+            if (stage == 1 && caps[1] <= caps[0]) break;
+            sweep_set &S = sweeps[2 + stage];
+            S.pairs = todo;
+            float ms[2] = {0, 0};
+            rc = malcs_sweep_optimal_runs(b, false, S.pairs, dist.data(), (int32_t)caps[stage], S.flat, S.first, ms);
+            if (rc) return rc;
+            ms_fwd += ms[0]; ms_reach += ms[1];
+            todo.clear();
+            for (size_t s = 0; s < S.pairs.size(); s++) {
+                const uint32_t pid = S.pairs[s];
+                if (dist[pid] < 0) { todo.push_back(pid); continue; }
+                has_runs[pid] = (uint8_t)(4 + stage);
+                sweep_slot[pid] = s;
+                MALCS_HIP(malcs_h2d(st, b->d_dist + pid, &dist[pid], 4));
+            }
+        }
+        std::vector<uint32_t> rest;
+        for (uint32_t pid : b->band_pairs) if (dist[pid] < 0) rest.push_back(pid);
+        if (!rest.empty()) {
+            std::vector<int32_t> got(rest.size());
+            rc = malcs_dist_band(b, rest, got.data());
+            if (rc) return rc;
+            for (size_t i = 0; i < rest.size(); i++) dist[rest[i]] = got[i];
+        }
     }
 
     // launch classes.  Short windows keep all their row groups resident (L lanes per pair, several pairs per
@@ -478,13 +521,8 @@ static int graph_batch(malcs_batch *b, const int64_t *shift, const int64_t *max_
     const int band_wmax = malcs_graph_max_band_words(b->n_planes);
     auto band_capacity = [](int W) { const int G = 64 * W; return 61 * (G + 1) - G - 64; };
     std::vector<launch_class> classes;
-    // [0]: long windows (workgroup of 512), [1]: windows below 4 096 rows at small distance (a wave each)
-    std::vector<uint32_t> sweep_pairs[2], sweep_flat[2];
-    std::vector<uint64_t> sweep_first[2], sweep_slot(N, 0);
     int64_t small_rows = 192;                           // shorter windows stay with the bit-vector kernels (64 pairs per wave)
     if (const char *e = getenv("MALCS_SWEEP_MIN_ROWS")) small_rows = atoll(e);
-    int64_t sweep_dmax = 32768;                         // beyond: the table (D^2 / 2 words) and the single workgroup stop paying
-    if (const char *e = getenv("MALCS_SWEEP_DMAX")) sweep_dmax = atoll(e);
     for (uint64_t i = 0; i < N; i++) {
         const uint32_t m = b->a_len[i], n = b->b_len[i];
         pair_graph &G = out->g[i];
@@ -492,16 +530,17 @@ static int graph_batch(malcs_batch *b, const int64_t *shift, const int64_t *max_
         const int64_t md = max_distance ? max_distance[i] : 0;
         if (md && G.distance > md) { G.status = MALCS_PAIR_MAX_DISTANCE_EXCEEDED; continue; }
         if (m == 0 || n == 0) continue;               // no DP needed: LLCS = 0
+        if (has_runs[i] >= 4) continue;               // its runs came with its distance
         int W = 0, logL = 0;
         bool band = false;
         if (m >= 4096u && G.distance <= sweep_dmax) {  // long and similar: the output-sensitive sweeps (malcs_sweep.hip)
-            sweep_pairs[0].push_back((uint32_t)i);
+            sweeps[0].pairs.push_back((uint32_t)i);
             has_runs[i] = 2;
             continue;
         }
         if (m < 4096u && (int64_t)m >= small_rows && G.distance <= std::min<int64_t>(sweep_dmax, malcs_sweep_small_dmax()) &&
             8 * G.distance <= (int64_t)std::max(m, n)) {   // similar windows: D + 1 steps of a wave instead of n columns
-            sweep_pairs[1].push_back((uint32_t)i);
+            sweeps[1].pairs.push_back((uint32_t)i);
             has_runs[i] = 3;
             continue;
         }
@@ -537,14 +576,14 @@ static int graph_batch(malcs_batch *b, const int64_t *shift, const int64_t *max_
     MALCS_HIP(hipMemGetInfo(&free_b, &total_b));
     const uint64_t budget_dwords = std::min<uint64_t>(free_b / 2, 64ull << 30) / 4;
 
-    float ms_fwd = 0, ms_reach = 0;
     for (int shape = 0; shape < 2; shape++) {
-        if (sweep_pairs[shape].empty()) continue;
+        sweep_set &S = sweeps[shape];
+        if (S.pairs.empty()) continue;
         float ms[2] = {0, 0};
-        int rc = malcs_sweep_optimal_runs(b, shape == 1, sweep_pairs[shape], dist.data(), sweep_flat[shape], sweep_first[shape], ms);
+        int rc = malcs_sweep_optimal_runs(b, shape == 1, S.pairs, dist.data(), 0, S.flat, S.first, ms);
         if (rc) return rc;
         ms_fwd += ms[0]; ms_reach += ms[1];
-        for (size_t s = 0; s < sweep_pairs[shape].size(); s++) sweep_slot[sweep_pairs[shape][s]] = s;
+        for (size_t s = 0; s < S.pairs.size(); s++) sweep_slot[S.pairs[s]] = s;
     }
     dev_buf<uint32_t> d_work, d_evcap, d_evcnt, d_scratch;
     dev_buf<uint64_t> d_scoff, d_evoff, d_outoff;
@@ -687,8 +726,8 @@ static int graph_batch(malcs_batch *b, const int64_t *shift, const int64_t *max_
             const double ta = trace ? now_ms() : 0;
             if (has_runs[i] >= 2) {                                      // runs straight from the sweep kernels
                 const uint64_t s = sweep_slot[i];
-                const std::vector<uint32_t> &flat = sweep_flat[has_runs[i] - 2];
-                const std::vector<uint64_t> &first = sweep_first[has_runs[i] - 2];
+                const std::vector<uint32_t> &flat = sweeps[has_runs[i] - 2].flat;
+                const std::vector<uint64_t> &first = sweeps[has_runs[i] - 2].first;
                 for (uint64_t r = first[s]; r < first[s + 1]; r++)
                     runs.push_back({flat[4 * r], flat[4 * r + 1], flat[4 * r + 2], flat[4 * r + 3]});
                 order_runs(runs, m, n);
@@ -711,7 +750,8 @@ static int graph_batch(malcs_batch *b, const int64_t *shift, const int64_t *max_
     unsigned nt = std::min<unsigned>(16u, std::max(1u, std::thread::hardware_concurrency()));
     {
         // threads pay from a few thousand runs on (a 10 kb tandem-repeat window alone builds 400 000 edges)
-        uint64_t load = (sweep_flat[0].size() + sweep_flat[1].size()) / 4;
+        uint64_t load = 0;
+        for (const sweep_set &S : sweeps) load += S.flat.size() / 4;
         for (uint64_t i = 0; i < N; i++) load += pair_events[i].n / 2;
         if (N < 64 && load < 4096) nt = 1;
         nt = (unsigned)std::min<uint64_t>(nt, std::max<uint64_t>(N, 1));

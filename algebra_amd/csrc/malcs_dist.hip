@@ -448,6 +448,15 @@ int malcs_dist_plan(malcs_batch *b)
 
 int malcs_dist_launch(malcs_batch *b)
 {
+    int rc = malcs_dist_launch_resident(b);
+    if (rc) return rc;
+    if (!b->band_pairs.empty()) return malcs_dist_band(b, b->band_pairs, nullptr);
+    return MALCS_OK;
+}
+
+// everything but the pairs beyond a resident pattern (b->band_pairs)
+int malcs_dist_launch_resident(malcs_batch *b)
+{
     // window class first, then the full-matrix kernel over whatever it left undecided
     if (b->diag.nlw) {
         int rc = malcs_diag_launch(b, true);
@@ -491,7 +500,6 @@ int malcs_dist_launch(malcs_batch *b)
                            b->d_b_off, b->d_b_len, b->d_order, k.first, k.count, logL, b->d_dist);
         MALCS_HIP(hipGetLastError());
     }
-    if (!b->band_pairs.empty()) return malcs_dist_band(b, b->band_pairs, nullptr);
     return MALCS_OK;
 }
 

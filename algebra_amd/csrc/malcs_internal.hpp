@@ -102,6 +102,7 @@ int malcs_diag_threshold(int nlw);
 // malcs_dist.hip
 int malcs_dist_plan(malcs_batch *b);
 int malcs_dist_launch(malcs_batch *b);
+int malcs_dist_launch_resident(malcs_batch *b);
 int malcs_dist_band(malcs_batch *b, const std::vector<uint32_t> &pairs, int32_t *host_out);
 
 // malcs_sweep.hip

@@ -636,7 +636,9 @@ int malcs_sweep_distances(malcs_batch *b, const std::vector<uint32_t> &pairs, in
 
 // Runs on the minimal alignments of the pairs in `work` (distances known: dist[pid]) by the two sweeps: backward
 // with the reach table, forward with emission.  Output as malcs_sweep_runs.  ms[0] += backward, ms[1] += forward pass.
-int malcs_sweep_optimal_runs(malcs_batch *b, bool small, const std::vector<uint32_t> &work, const int32_t *dist,
+// With unknown_cap > 0 the distances are not known yet: the backward sweep runs up to that many edits, writes what
+// it finds to dist[pid] (-1: more than unknown_cap, no runs for that pair) and sizes its table for the cap.
+int malcs_sweep_optimal_runs(malcs_batch *b, bool small, const std::vector<uint32_t> &work, int32_t *dist, int32_t unknown_cap,
                              std::vector<uint32_t> &out_runs, std::vector<uint64_t> &out_first, float *ms)
 {
     const int lds_diags = small ? SMALL_DIAGS : BIG_DIAGS;
@@ -655,7 +657,8 @@ int malcs_sweep_optimal_runs(malcs_batch *b, bool small, const std::vector<uint3
         uint64_t tab_total = 0;
         size_t end = pos;
         while (end < work.size()) {
-            const int64_t D = dist[work[end]];
+            const int64_t D = unknown_cap ? std::min<int64_t>(unknown_cap, (int64_t)b->a_len[work[end]] + b->b_len[work[end]])
+                                          : dist[work[end]];
             const uint64_t need = (uint64_t)(D + 1) * (uint64_t)(D + 2) / 2;
             if (end > pos && tab_total + need > budget) break;
             if (need > budget) {
@@ -683,7 +686,9 @@ int malcs_sweep_optimal_runs(malcs_batch *b, bool small, const std::vector<uint3
         MALCS_HIP(malcs_h2d(st, d_dists.p, dists.data(), cnt * 4ull));
         MALCS_HIP(malcs_h2d(st, d_tab_off.p, tab_off.data(), cnt * 8ull));
         MALCS_HIP(malcs_h2d(st, d_fr_off.p, fr_off_b.data(), cnt * 8ull));
-        MALCS_HIP(hipMemsetAsync(d_tab.p, 0xff, tab_total * 4ull, st));       // an entry never written reaches nothing
+        // an entry never written reaches nothing (with a cap instead of the distance the table may be GBs, and every
+        // entry the forward pass looks up has been written: skip the fill)
+        if (!unknown_cap) MALCS_HIP(hipMemsetAsync(d_tab.p, 0xff, tab_total * 4ull, st));
         MALCS_HIP(hipEventRecord(ctx->ev0, st));
         int rc = launch_reach_any(b, small, true, cnt, d_work.p, d_dists.p, d_fr.p, d_fr_off.p, d_tab.p, d_tab_off.p, d_found.p);
         if (rc) return rc;
@@ -694,61 +699,90 @@ int malcs_sweep_optimal_runs(malcs_batch *b, bool small, const std::vector<uint3
         float t = 0;
         MALCS_HIP(hipEventElapsedTime(&t, ctx->ev0, ctx->ev1));
         ms[0] += t;
-        std::vector<uint32_t> cap(cnt), got(cnt);
-        std::vector<uint64_t> off(cnt);
-        uint64_t total = 0;
-        for (uint32_t s = 0; s < cnt; s++) {
-            if (found[s] != dists[s]) {
-                malcs_set_error("pair %u: the backward sweep found distance %d, expected %d (internal error)", work[pos + s], found[s], dists[s]);
+        // the pairs that go on to the forward pass (all of them when the distances were known)
+        const uint32_t all = cnt;
+        std::vector<uint32_t> keep, fwd_work;
+        std::vector<uint64_t> fwd_tab_off;
+        nd_fwd.clear();
+        for (uint32_t s = 0; s < all; s++) {
+            const uint32_t pid = work[pos + s];
+            if (unknown_cap) {
+                dist[pid] = found[s];
+                if (found[s] < 0) continue;
+            } else if (found[s] != dists[s]) {
+                malcs_set_error("pair %u: the backward sweep found distance %d, expected %d (internal error)", pid, found[s], dists[s]);
                 return MALCS_ERR_INTERNAL;
             }
-            cap[s] = 64u + 16u * (uint32_t)dists[s];
-            off[s] = total; total += cap[s];
+            keep.push_back(s); fwd_work.push_back(pid); fwd_tab_off.push_back(tab_off[s]);
+            nd_fwd.push_back((int64_t)found[s] + 3);
         }
-        MALCS_HIP(malcs_h2d(st, d_fr_off.p, fr_off_f.data(), cnt * 8ull));
+        const uint32_t cntf = (uint32_t)keep.size();
+        if (!cntf) { for (uint32_t s = 0; s < all; s++) out_first[pos + s + 1] = out_runs.size() / 4; pos = end; continue; }
+        std::vector<int32_t> fwd_dists(cntf);
+        for (uint32_t f = 0; f < cntf; f++) fwd_dists[f] = found[keep[f]];
+        const uint64_t fr_f2 = fr_layout(nd_fwd, lds_diags, fr_off_f);
+        if (fr_f2 > std::max(fr_b, fr_f)) { malcs_set_error("sweep scratch too small (internal error)"); return MALCS_ERR_INTERNAL; }
+        MALCS_HIP(malcs_h2d(st, d_work.p, fwd_work.data(), cntf * 4ull));
+        MALCS_HIP(malcs_h2d(st, d_dists.p, fwd_dists.data(), cntf * 4ull));
+        MALCS_HIP(malcs_h2d(st, d_tab_off.p, fwd_tab_off.data(), cntf * 8ull));
+        std::vector<uint32_t> cap(cntf), got(cntf);
+        std::vector<uint64_t> off(cntf);
+        uint64_t total = 0;
+        for (uint32_t f = 0; f < cntf; f++) {
+            cap[f] = 64u + 16u * (uint32_t)fwd_dists[f];
+            off[f] = total; total += cap[f];
+        }
+        MALCS_HIP(malcs_h2d(st, d_fr_off.p, fr_off_f.data(), cntf * 8ull));
         for (int attempt = 0;; attempt++) {
             if (d_out.p) { hipFree(d_out.p); d_out.p = nullptr; }
             if (d_out.alloc(total)) { malcs_set_error("device allocation failed (%llu runs)", (unsigned long long)total); return MALCS_ERR_NOMEM; }
-            MALCS_HIP(malcs_h2d(st, d_cap.p, cap.data(), cnt * 4ull));
-            MALCS_HIP(malcs_h2d(st, d_out_off.p, off.data(), cnt * 8ull));
+            MALCS_HIP(malcs_h2d(st, d_cap.p, cap.data(), cntf * 4ull));
+            MALCS_HIP(malcs_h2d(st, d_out_off.p, off.data(), cntf * 8ull));
             MALCS_HIP(hipEventRecord(ctx->ev1, st));
             switch (b->n_planes) {
-            case 2: rc = launch_runs<2>(b, small, cnt, d_work.p, d_dists.p, d_fr.p, d_fr_off.p, d_tab.p, d_tab_off.p, d_out.p, d_out_off.p, d_cap.p, d_cnt.p); break;
-            case 3: rc = launch_runs<3>(b, small, cnt, d_work.p, d_dists.p, d_fr.p, d_fr_off.p, d_tab.p, d_tab_off.p, d_out.p, d_out_off.p, d_cap.p, d_cnt.p); break;
-            case 4: rc = launch_runs<4>(b, small, cnt, d_work.p, d_dists.p, d_fr.p, d_fr_off.p, d_tab.p, d_tab_off.p, d_out.p, d_out_off.p, d_cap.p, d_cnt.p); break;
-            case 8: rc = launch_runs<8>(b, small, cnt, d_work.p, d_dists.p, d_fr.p, d_fr_off.p, d_tab.p, d_tab_off.p, d_out.p, d_out_off.p, d_cap.p, d_cnt.p); break;
+            case 2: rc = launch_runs<2>(b, small, cntf, d_work.p, d_dists.p, d_fr.p, d_fr_off.p, d_tab.p, d_tab_off.p, d_out.p, d_out_off.p, d_cap.p, d_cnt.p); break;
+            case 3: rc = launch_runs<3>(b, small, cntf, d_work.p, d_dists.p, d_fr.p, d_fr_off.p, d_tab.p, d_tab_off.p, d_out.p, d_out_off.p, d_cap.p, d_cnt.p); break;
+            case 4: rc = launch_runs<4>(b, small, cntf, d_work.p, d_dists.p, d_fr.p, d_fr_off.p, d_tab.p, d_tab_off.p, d_out.p, d_out_off.p, d_cap.p, d_cnt.p); break;
+            case 8: rc = launch_runs<8>(b, small, cntf, d_work.p, d_dists.p, d_fr.p, d_fr_off.p, d_tab.p, d_tab_off.p, d_out.p, d_out_off.p, d_cap.p, d_cnt.p); break;
             default: malcs_set_error("unsupported plane count %d", b->n_planes); rc = MALCS_ERR_ARG;
             }
             if (rc) return rc;
             MALCS_HIP(hipEventRecord(ctx->ev2, st));
-            MALCS_HIP(malcs_d2h(st, got.data(), d_cnt.p, cnt * 4ull));
+            MALCS_HIP(malcs_d2h(st, got.data(), d_cnt.p, cntf * 4ull));
             MALCS_HIP(malcs_sync(st));
             MALCS_HIP(hipEventElapsedTime(&t, ctx->ev1, ctx->ev2));
             ms[1] += t;
             bool overflow = false;
-            for (uint32_t s = 0; s < cnt; s++) if (got[s] > cap[s]) overflow = true;
+            for (uint32_t s = 0; s < cntf; s++) if (got[s] > cap[s]) overflow = true;
             if (!overflow) break;
             if (attempt) { malcs_set_error("run buffer overflow persisted after a resize"); return MALCS_ERR_INTERNAL; }
             total = 0;                                                        // the counts are exact: size every region to its count, redo
-            for (uint32_t s = 0; s < cnt; s++) { cap[s] = std::max(cap[s], got[s]); off[s] = total; total += cap[s]; }
+            for (uint32_t s = 0; s < cntf; s++) { cap[s] = std::max(cap[s], got[s]); off[s] = total; total += cap[s]; }
         }
         // gather the used parts on the device, bring them home in one copy
         size_t base = out_runs.size();
-        std::vector<uint64_t> packed_off(cnt);
+        std::vector<uint64_t> packed_off(cntf);
         uint64_t kept = 0;
-        for (uint32_t s = 0; s < cnt; s++) { packed_off[s] = kept; kept += got[s]; }
+        for (uint32_t s = 0; s < cntf; s++) { packed_off[s] = kept; kept += got[s]; }
         out_runs.resize(base + kept * 4);
         if (kept) {
             dbuf<uint4> d_packed;
             dbuf<uint64_t> d_packed_off;
-            if (d_packed.alloc(kept) || d_packed_off.alloc(cnt)) { malcs_set_error("device allocation failed (%llu runs)", (unsigned long long)kept); return MALCS_ERR_NOMEM; }
-            MALCS_HIP(malcs_h2d(st, d_packed_off.p, packed_off.data(), cnt * 8ull));
-            rc = malcs_graph_launch_compact(ctx, d_out.p, d_out_off.p, d_cnt.p, d_packed_off.p, cnt, d_packed.p);
+            if (d_packed.alloc(kept) || d_packed_off.alloc(cntf)) { malcs_set_error("device allocation failed (%llu runs)", (unsigned long long)kept); return MALCS_ERR_NOMEM; }
+            MALCS_HIP(malcs_h2d(st, d_packed_off.p, packed_off.data(), cntf * 8ull));
+            rc = malcs_graph_launch_compact(ctx, d_out.p, d_out_off.p, d_cnt.p, d_packed_off.p, cntf, d_packed.p);
             if (rc) return rc;
             MALCS_HIP(malcs_d2h(st, out_runs.data() + base, d_packed.p, kept * 16ull));
             MALCS_HIP(malcs_sync(st));
         }
-        for (uint32_t s = 0; s < cnt; s++) out_first[pos + s + 1] = (base >> 2) + packed_off[s] + got[s];
+        {
+            uint64_t last = base >> 2;                                        // a pair without runs ends where its predecessor ends
+            uint32_t f = 0;
+            for (uint32_t s = 0; s < all; s++) {
+                if (f < cntf && keep[f] == s) { last = (base >> 2) + packed_off[f] + got[f]; f++; }
+                out_first[pos + s + 1] = last;
+            }
+        }
         pos = end;
     }
     return MALCS_OK;
