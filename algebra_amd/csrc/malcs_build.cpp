@@ -523,6 +523,8 @@ static int graph_batch(malcs_batch *b, const int64_t *shift, const int64_t *max_
     std::vector<launch_class> classes;
     int64_t small_rows = 192;                           // shorter windows stay with the bit-vector kernels (64 pairs per wave)
     if (const char *e = getenv("MALCS_SWEEP_MIN_ROWS")) small_rows = atoll(e);
+    int64_t small_ratio = 8;                            // ... as do windows further apart than length / 8
+    if (const char *e = getenv("MALCS_SWEEP_RATIO")) small_ratio = atoll(e);
     for (uint64_t i = 0; i < N; i++) {
         const uint32_t m = b->a_len[i], n = b->b_len[i];
         pair_graph &G = out->g[i];
@@ -539,7 +541,7 @@ static int graph_batch(malcs_batch *b, const int64_t *shift, const int64_t *max_
             continue;
         }
         if (m < 4096u && (int64_t)m >= small_rows && G.distance <= std::min<int64_t>(sweep_dmax, malcs_sweep_small_dmax()) &&
-            8 * G.distance <= (int64_t)std::max(m, n)) {   // similar windows: D + 1 steps of a wave instead of n columns
+            small_ratio * G.distance <= (int64_t)std::max(m, n)) {   // similar windows: D + 1 steps of a wave instead of n columns
             sweeps[1].pairs.push_back((uint32_t)i);
             has_runs[i] = 3;
             continue;

@@ -26,23 +26,33 @@ def encode_pairs(pairs):
     Sequences are interned by identity/value so that a sequence shared by many pairs is stored once.
     """
     index = {}
-    arrays = []
+    unique = []
     refs = []
     for pair in pairs:
         for seq in pair:
             slot = index.get(seq)
             if slot is None:
-                slot = index[seq] = len(arrays)
-                arrays.append(_raw(seq))
+                slot = index[seq] = len(unique)
+                unique.append(seq)
             refs.append(slot)
-    lens = np.array([len(x) for x in arrays], dtype=np.uint64)
-    offs = np.zeros(len(arrays) + 1, dtype=np.uint64)
+    lens = np.fromiter((len(x) for x in unique), dtype=np.uint64, count=len(unique))
+    offs = np.zeros(len(unique) + 1, dtype=np.uint64)
     np.cumsum(lens, out=offs[1:])
-    if arrays and any(x.dtype != np.uint8 for x in arrays):
-        flat = np.concatenate([x.astype(np.uint32) for x in arrays]) if arrays else np.zeros(0, np.uint32)
+    flat = None
+    if unique and all(isinstance(x, str) for x in unique):
+        try:                                   # one encode for the whole batch (Latin-1 covers every alphabet seen so far)
+            flat = np.frombuffer("".join(unique).encode("latin-1"), dtype=np.uint8)
+        except UnicodeEncodeError:
+            flat = None
+    if flat is None:
+        arrays = [_raw(x) for x in unique]
+        if arrays and any(x.dtype != np.uint8 for x in arrays):
+            flat = np.concatenate([x.astype(np.uint32) for x in arrays])
+        else:
+            flat = np.concatenate(arrays) if arrays else np.zeros(0, np.uint8)
+    if flat.dtype != np.uint8:
         present = np.unique(flat)
     else:
-        flat = np.concatenate(arrays) if arrays else np.zeros(0, np.uint8)
         present = np.nonzero(np.bincount(flat, minlength=256))[0]
     dna = [ord(ch) for ch in "ACGT"]
     others = [int(v) for v in present if int(v) not in dna]
