@@ -84,6 +84,13 @@ def extract_sequence(reference, observed):
     return canonical(graph), graph
 
 
+def extract_sequence_batch(pairs, ctx=None):
+    """`[extract_sequence(reference, observed) for reference, observed in pairs]` with all LCS graphs
+    built in shared device batches (`LCSgraph.from_sequence_batch`)."""
+    graphs = LCSgraph.from_sequence_batch(pairs, ctx=ctx)
+    return [(canonical(graph), graph) for graph in graphs]
+
+
 def extract_supremal(reference, supremal):
     """Canonical allele and graph for a supremal variant (reference :124-128)."""
     graph = LCSgraph.from_supremal(reference, supremal)

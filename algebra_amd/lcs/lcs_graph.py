@@ -182,10 +182,31 @@ class LCSgraph:
         """`[from_variant(reference, allele, offset) for allele in alleles]` with the windows of every
         widening round built in one device batch (reference lcs_graph.py:113-123 runs the rounds per
         allele; alleles are independent, so the rounds can be shared)."""
-        results = [None] * len(alleles)
-        pending = []                                   # (index, delins Variant, offset)
+        return cls._from_alleles_batch([(reference, variants) for variants in alleles], offset, ctx)
+
+    @classmethod
+    def from_sequence_batch(cls, pairs, ctx=None):
+        """`[from_sequence(reference, observed) for reference, observed in pairs]` (reference
+        lcs_graph.py:63-70) in shared device batches: every pair is trimmed to one delins variant on its
+        own reference, then treated as `from_variant` treats an allele."""
+        items = []
+        for reference, observed in pairs:
+            if reference == observed:
+                items.append((reference, []))
+                continue
+            prefix_len, suffix_len = trim(reference, observed)
+            items.append((reference, [Variant(prefix_len, len(reference) - suffix_len,
+                                              observed[prefix_len:len(observed) - suffix_len])]))
+        return cls._from_alleles_batch(items, 10, ctx)
+
+    @classmethod
+    def _from_alleles_batch(cls, items, offset, ctx):
+        """items: [(reference, variants), ...]; the window-widening loop of `from_variant`, round by round
+        for all items at once."""
+        results = [None] * len(items)
+        pending = []                                   # (index, reference, delins Variant, offset)
         trivial = []
-        for idx, variants in enumerate(alleles):
+        for idx, (reference, variants) in enumerate(items):
             if not variants:
                 trivial.append(idx)
                 continue
@@ -196,14 +217,14 @@ class LCSgraph:
                 trivial.append(idx)
                 continue
             allele = Variant(start, end, observed)
-            pending.append((idx, allele, max(offset, len(allele) // 2, 1)))
+            pending.append((idx, reference, allele, max(offset, len(allele) // 2, 1)))
         if trivial:
             empty = cls.batch([("", "")], ctx=ctx)[0]
             for idx in trivial:
                 results[idx] = empty
         while pending:
             windows, shifts, bounds = [], [], []
-            for _, allele, off in pending:
+            for _, reference, allele, off in pending:
                 lo = max(0, allele.start - off)
                 hi = min(len(reference), allele.end + off)
                 windows.append((reference[lo:hi], reference[lo:allele.start] + allele.sequence + reference[allele.end:hi]))
@@ -211,13 +232,13 @@ class LCSgraph:
                 bounds.append((lo, hi))
             graphs = cls.batch(windows, shifts, ctx=ctx)
             again = []
-            for (idx, allele, off), graph, (lo, hi) in zip(pending, graphs, bounds):
+            for (idx, reference, allele, off), graph, (lo, hi) in zip(pending, graphs, bounds):
                 inside_left = graph.supremal.start > lo or graph.supremal.start == 0
                 inside_right = graph.supremal.end < hi or graph.supremal.end == len(reference)
                 if inside_left and inside_right:
                     results[idx] = graph
                 else:
-                    again.append((idx, allele, off * 2))
+                    again.append((idx, reference, allele, off * 2))
             pending = again
         return results
 

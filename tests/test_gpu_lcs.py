@@ -85,6 +85,7 @@ def use_path(monkeypatch, path):
         monkeypatch.setenv("MALCS_SWEEP_DCAP", "0")
     elif path == "sweep-all":                  # also the shortest windows through the one-wave sweeps
         monkeypatch.setenv("MALCS_SWEEP_MIN_ROWS", "1")
+        monkeypatch.setenv("MALCS_SWEEP_RATIO", "0")       # ... and the divergent ones
     elif path == "mixed":                      # sweeps give up early: their results and the band kernels' in one batch
         monkeypatch.setenv("MALCS_SWEEP_DMAX", "700")
         monkeypatch.setenv("MALCS_SWEEP_DCAP", "700")
@@ -280,7 +281,7 @@ def test_graph_random_medium(native):
 def test_graph_arrays_vs_oracle(native, path, monkeypatch):
     """Straight through the C-ABI (no facade objects): arrays equal the oracle's, runs are a
     sub-list of the oracle's level lists.  Windows below 4 096 rows: bit-vector kernels ("band" = sweeps off) and
-    one-wave sweeps (by default from 192 rows and distance <= length / 8 on, "sweep-all" from 1 row on)."""
+    one-wave sweeps (by default from 192 rows and distance <= length / 8 on, "sweep-all" from 1 row on at any distance <= 510)."""
     from oracle import oracle as O
     from algebra_amd.lcs.encoding import encode_pairs
     use_path(monkeypatch, path)

@@ -134,6 +134,21 @@ def test_from_variant_batch_equals_singles():
         assert graph_record(got) == rec["graph"]
 
 
+def test_extract_sequence_batch_equals_singles():
+    """`extract_sequence_batch` / `LCSgraph.from_sequence_batch`: every reference-test pair in shared batches."""
+    from algebra_amd.extractor import extract_sequence_batch, to_hgvs
+    from util import graph_record
+    records = REF["sequences"] + SEQS["sequences"][:60]
+    got = extract_sequence_batch([(rec["reference"], rec["observed"]) for rec in records])
+    from util import assert_graph
+    for rec, (variants, graph) in zip(records, got):
+        assert_graph(rec, graph_record(graph))
+        if "canonical" in rec:
+            assert [[v.start, v.end, v.sequence] for v in variants] == rec["canonical"]
+        if "hgvs" in rec:
+            assert to_hgvs(variants, rec["reference"]) == rec["hgvs"]
+
+
 def test_extract_sequence_canonical_and_hgvs():
     from algebra_amd.extractor import extract_sequence, to_hgvs
     for rec in REF["sequences"] + SEQS["sequences"]:
