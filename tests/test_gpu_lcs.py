@@ -219,6 +219,24 @@ def test_empty_batch_and_bad_arguments(native):
         native.Batch(ctx, np.zeros(4, np.uint8), [0], [10], [0], [2], 4)     # sequence outside the buffer
     with pytest.raises(native.MalcsError):
         native.Batch(ctx, np.zeros(4, np.uint8), [0], [2], [0], [2], 0)      # n_symbols out of range
+    # empty batches and NULL handles through every family
+    import ctypes
+    empty = native.Batch(ctx, np.zeros(1, np.uint8), [], [], [], [], 4)
+    assert empty.distances().tolist() == []
+    for res in (empty.graphs(), empty.lcs_nodes()):
+        assert res.counts.shape == (0, 4)
+        res.close()
+    empty.close()
+    handle = ctypes.c_void_p()
+    assert native.lib.malcs_lcs_graph_batch(None, None, None, ctypes.byref(handle)) != 0
+    assert native.lib.malcs_lcs_nodes_batch(None, None, None, ctypes.byref(handle)) != 0
+    assert native.lib.malcs_relmatrix_create(None, 0, None, None, None, None, 16, 0, 1, ctypes.byref(handle)) != 0
+    assert b"argument" in native.lib.malcs_last_error()
+    none = native.RelationMatrix(ctx, [], [], [], [], 16)
+    assert none.pending().shape == (0, 2) and none.assemble().shape == (0, 0)
+    none.close()
+    with pytest.raises(native.MalcsError):
+        native.RelationMatrix(ctx, [0], [1], [0], [1], 16, rank=2, world=2)   # rank outside the world
 
 
 # ---------------------------------------------------------------------------------------------
