@@ -21,26 +21,17 @@ def compare_batch(reference, lhs_alleles, rhs_alleles, offset=10):
     return graph_based.compare_batch(reference, graphs[:n], graphs[n:])
 
 
-def are_equivalent(reference, lhs, rhs):
-    """Check if two variants are equivalent."""
-    return compare(reference, lhs, rhs) == Relation.EQUIVALENT
+def _predicate(name, relation, doc):
+    def test(reference, lhs, rhs):
+        return compare(reference, lhs, rhs) is relation
+    test.__name__ = test.__qualname__ = name
+    test.__doc__ = doc
+    return test
 
 
-def contains(reference, lhs, rhs):
-    """Check if `lhs` contains `rhs`."""
-    return compare(reference, lhs, rhs) == Relation.CONTAINS
-
-
-def is_contained(reference, lhs, rhs):
-    """Check if `lhs` is contained in `rhs`."""
-    return compare(reference, lhs, rhs) == Relation.IS_CONTAINED
-
-
-def are_disjoint(reference, lhs, rhs):
-    """Check if two variants are disjoint."""
-    return compare(reference, lhs, rhs) == Relation.DISJOINT
-
-
-def have_overlap(reference, lhs, rhs):
-    """Check if two variants overlap."""
-    return compare(reference, lhs, rhs) == Relation.OVERLAP
+# the reference's five predicates (variant_based.py:55-77), each `compare(...) == <one relation>`
+are_equivalent = _predicate("are_equivalent", Relation.EQUIVALENT, "Are the alleles `lhs` and `rhs` equivalent?")
+contains = _predicate("contains", Relation.CONTAINS, "Does allele `lhs` contain allele `rhs`?")
+is_contained = _predicate("is_contained", Relation.IS_CONTAINED, "Is allele `lhs` contained in allele `rhs`?")
+are_disjoint = _predicate("are_disjoint", Relation.DISJOINT, "Are the alleles `lhs` and `rhs` disjoint?")
+have_overlap = _predicate("have_overlap", Relation.OVERLAP, "Do the alleles `lhs` and `rhs` overlap?")
