@@ -69,6 +69,8 @@ def _load():
         "malcs_relmatrix_resolve": (c.c_int, [vp, vp]),
         "malcs_relmatrix_tiles": (c.c_int, [vp, vp]),
         "malcs_relmatrix_assemble": (c.c_int, [vp, vp, vp]),
+        "malcs_relmatrix_tiles_device": (c.c_int, [vp, P(vp), P(u64)]),
+        "malcs_relmatrix_assemble_device": (c.c_int, [vp, vp, vp]),
     }
     for name, (res, args) in sig.items():
         fn = getattr(lib, name)          # AttributeError here = header and library disagree
@@ -316,6 +318,20 @@ class RelationMatrix:
         out = np.zeros((self.per_rank, self.tile, self.tile), dtype=np.uint8)
         check(lib.malcs_relmatrix_tiles(self.handle, ptr(out)))
         return out
+
+    def tiles_device(self):
+        """(device address, bytes) of this rank's label block: what a device-side all-gather sends."""
+        address, nbytes = ctypes.c_void_p(), ctypes.c_uint64()
+        check(lib.malcs_relmatrix_tiles_device(self.handle, ctypes.byref(address), ctypes.byref(nbytes)))
+        return address.value, nbytes.value
+
+    def assemble_device(self, address, nbytes):
+        """`assemble` from gathered blocks that already sit on this handle's device (a completed collective)."""
+        if nbytes != self.world * self.per_rank * self.tile * self.tile:
+            raise ValueError("gathered label block has the wrong size")
+        full = np.zeros((self.n, self.n), dtype=np.uint8)
+        check(lib.malcs_relmatrix_assemble_device(self.handle, ctypes.c_void_p(address), ptr(full)))
+        return full
 
     def assemble(self, gathered=None):
         full = np.zeros((self.n, self.n), dtype=np.uint8)

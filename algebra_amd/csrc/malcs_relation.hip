@@ -230,27 +230,56 @@ int malcs_relmatrix_tiles(const malcs_relmatrix *h, uint8_t *labels)
     return MALCS_OK;
 }
 
+int malcs_relmatrix_tiles_device(const malcs_relmatrix *h, const void **d_labels, uint64_t *bytes)
+{
+    if (!h || !d_labels || !bytes) { malcs_set_error("NULL argument"); return MALCS_ERR_ARG; }
+    MALCS_HIP(hipSetDevice(h->ctx->device));
+    MALCS_HIP(malcs_sync(h->ctx->stream));       // resolve() may still be scattering verdicts
+    *d_labels = h->labels.p;
+    *bytes = (uint64_t)h->per_rank * h->tile * h->tile;
+    return MALCS_OK;
+}
+
+// `d_src`: the gathered blocks on the device, or NULL for this rank's own block (world == 1)
+static int relmatrix_assemble(malcs_relmatrix *h, const uint8_t *d_src, uint8_t *full)
+{
+    hipStream_t st = h->ctx->stream;
+    dev<uint8_t> d_full;
+    if (d_full.alloc((size_t)h->n * h->n)) { malcs_set_error("device allocation failed (%u x %u labels)", h->n, h->n); return MALCS_ERR_NOMEM; }
+    hipLaunchKernelGGL(k_relation_assemble, dim3(h->n, (h->n + 255u) / 256u), dim3(256), 0, st, h->n, h->tile, h->blocks, h->world,
+                       h->per_rank, d_src ? d_src : h->labels.p, d_full.p);
+    MALCS_HIP(hipGetLastError());
+    MALCS_HIP(malcs_d2h(st, full, d_full.p, (size_t)h->n * h->n));
+    MALCS_HIP(malcs_sync(st));
+    return MALCS_OK;
+}
+
 int malcs_relmatrix_assemble(malcs_relmatrix *h, const uint8_t *gathered, uint8_t *full)
 {
     if (!h || (h->n && !full) || (h->world > 1 && !gathered)) { malcs_set_error("NULL argument"); return MALCS_ERR_ARG; }
     if (!h->n) return MALCS_OK;
     MALCS_HIP(hipSetDevice(h->ctx->device));
-    hipStream_t st = h->ctx->stream;
     const size_t bytes = (size_t)h->world * h->per_rank * h->tile * h->tile;
-    dev<uint8_t> d_gathered, d_full;
-    const uint8_t *src = h->labels.p;
-    if (d_full.alloc((size_t)h->n * h->n)) { malcs_set_error("device allocation failed (%u x %u labels)", h->n, h->n); return MALCS_ERR_NOMEM; }
+    dev<uint8_t> d_gathered;
     if (gathered) {
         if (d_gathered.alloc(bytes)) { malcs_set_error("device allocation failed (%llu gathered label bytes)", (unsigned long long)bytes); return MALCS_ERR_NOMEM; }
-        MALCS_HIP(malcs_h2d(st, d_gathered.p, gathered, bytes));
-        src = d_gathered.p;
+        MALCS_HIP(malcs_h2d(h->ctx->stream, d_gathered.p, gathered, bytes));
     }
-    hipLaunchKernelGGL(k_relation_assemble, dim3(h->n, (h->n + 255u) / 256u), dim3(256), 0, st, h->n, h->tile, h->blocks, h->world,
-                       h->per_rank, src, d_full.p);
-    MALCS_HIP(hipGetLastError());
-    MALCS_HIP(malcs_d2h(st, full, d_full.p, (size_t)h->n * h->n));
-    MALCS_HIP(malcs_sync(st));
-    return MALCS_OK;
+    return relmatrix_assemble(h, d_gathered.p, full);
+}
+
+int malcs_relmatrix_assemble_device(malcs_relmatrix *h, const void *d_gathered, uint8_t *full)
+{
+    if (!h || (h->n && !full) || !d_gathered) { malcs_set_error("NULL argument"); return MALCS_ERR_ARG; }
+    if (!h->n) return MALCS_OK;
+    MALCS_HIP(hipSetDevice(h->ctx->device));
+    hipPointerAttribute_t attr;
+    if (hipPointerGetAttributes(&attr, d_gathered) != hipSuccess || attr.type != hipMemoryTypeDevice || attr.device != h->ctx->device) {
+        (void)hipGetLastError();
+        malcs_set_error("gathered labels are not device memory of device %d", h->ctx->device);
+        return MALCS_ERR_ARG;
+    }
+    return relmatrix_assemble(h, (const uint8_t *)d_gathered, full);
 }
 
 }  // extern "C"

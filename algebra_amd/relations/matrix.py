@@ -36,6 +36,13 @@ def shard(items, rank, world):
     return items[rank::world]
 
 
+class _DeviceBytes:
+    """A span of device memory owned by the library, as the CUDA array interface torch reads."""
+
+    def __init__(self, address, nbytes):
+        self.__cuda_array_interface__ = {"shape": (nbytes,), "typestr": "|u1", "data": (address, False), "version": 2}
+
+
 class Prepared:
     """Per-variant arrays for the pre-filters: interval, distance, a number per distinct supremal
     (equal supremals <=> equal keys, graph_based.py:51) and one bit per symbol of the inserted
@@ -62,7 +69,7 @@ class Prepared:
         self.symmask = np.array(masks, dtype=np.uint64)
 
 
-def compare_matrix(reference, graphs, tile=256, group=None, distance_fn=None, stats=None, tiles_cls=None):
+def compare_matrix(reference, graphs, tile=256, group=None, distance_fn=None, stats=None, tiles_cls=None, gather_always=False):
     """uint8 matrix L with L[i, j] = code of compare(reference, graphs[i], graphs[j]).
 
     Codes follow the order of `Relation` (0 equivalent, 1 contains, 2 is_contained, 3 overlap,
@@ -71,7 +78,8 @@ def compare_matrix(reference, graphs, tile=256, group=None, distance_fn=None, st
 
     `distance_fn` and `tiles_cls` exist for the host-logic tests (CPU, gloo): they inject
     distances computed elsewhere and a numpy restatement of the tile kernels.  The product path
-    leaves both unset and runs on the device.
+    leaves both unset and runs on the device.  `gather_always` runs the collective in a group of one rank as well
+    (tests of the RCCL path on a single GPU).
     """
     if distance_fn is None:
         from ..lcs import edit_distance_batch as distance_fn
@@ -135,13 +143,27 @@ def compare_matrix(reference, graphs, tile=256, group=None, distance_fn=None, st
 
         # all-gather of the label tiles
         gathered = None
-        if world > 1:
+        if world > 1 or gather_always:
             import torch
-            mine = tiles.tiles()
             backend = dist.get_backend(group)
-            device = torch.device("cuda", torch.cuda.current_device()) if backend == "nccl" else torch.device("cpu")
-            send = torch.from_numpy(mine).to(device)
-            recv = torch.empty((world * mine.shape[0], tile, tile), dtype=torch.uint8, device=device)
+            if backend == "nccl" and hasattr(tiles, "tiles_device"):
+                # RCCL reads this rank's block where the kernels wrote it and writes the gathered blocks where
+                # the assembly kernel reads them: no host staging
+                address, nbytes = tiles.tiles_device()
+                device = torch.device("cuda", torch.cuda.current_device())
+                send = torch.as_tensor(_DeviceBytes(address, nbytes), device=device)
+                recv = torch.empty(world * nbytes, dtype=torch.uint8, device=device)
+                dist.all_gather_into_tensor(recv, send, group=group)
+                torch.cuda.current_stream(device).synchronize()
+                lap("all_gather")
+                full = tiles.assemble_device(recv.data_ptr(), recv.numel())
+                lap("assemble")
+                return full
+            mine = tiles.tiles()
+            send = torch.from_numpy(mine)
+            recv = torch.empty((world * mine.shape[0], tile, tile), dtype=torch.uint8)
+            if backend == "nccl":
+                send, recv = send.cuda(), recv.cuda()
             dist.all_gather_into_tensor(recv, send, group=group)
             gathered = recv.cpu().numpy()
             lap("all_gather")

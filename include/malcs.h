@@ -180,6 +180,12 @@ int malcs_relmatrix_pending(const malcs_relmatrix *m, int64_t *pairs2);
 int malcs_relmatrix_resolve(malcs_relmatrix *m, const uint8_t *codes);
 int malcs_relmatrix_tiles(const malcs_relmatrix *m, uint8_t *labels);
 int malcs_relmatrix_assemble(malcs_relmatrix *m, const uint8_t *gathered, uint8_t *full);
+/* The same two steps for a caller whose collective runs on device memory (RCCL): `tiles_device` hands out the
+ * device address of this rank's label block (owned by the handle, valid until destroy; the library's stream has
+ * been drained, so any stream may read it), `assemble_device` takes the gathered blocks as a device address on
+ * the handle's device (the caller has completed the collective that wrote them).  No host staging of the tiles. */
+int malcs_relmatrix_tiles_device(const malcs_relmatrix *m, const void **d_labels, uint64_t *bytes);
+int malcs_relmatrix_assemble_device(malcs_relmatrix *m, const void *d_gathered, uint8_t *full);
 
 #ifdef __cplusplus
 }

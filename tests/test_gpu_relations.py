@@ -308,3 +308,42 @@ def test_compare_matrix_two_ranks_on_the_device():
         assert p.exitcode == 0
     assert [r[1] for r in results] == [True, True]
     assert abs(results[0][2] - results[1][2]) <= 1 and results[0][3] + results[1][3] > 0
+
+
+def _matrix_rccl_rank(port, out):
+    import os
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), MALCS_DEVICE="0")
+    import torch
+    import torch.distributed as dist
+    torch.cuda.set_device(0)
+    dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", 0))
+    try:
+        from algebra_amd.lcs import LCSgraph
+        from algebra_amd.relations import compare_matrix
+        from algebra_amd.variants import Variant
+        ok = []
+        for case in SEQS["matrices"]:
+            graphs = LCSgraph.from_variant_batch(case["reference"], [[Variant(*v)] for v in case["variants"]])
+            for tile in (8, 256):
+                stats = {}
+                labels = compare_matrix(case["reference"], graphs, tile=tile, stats=stats, gather_always=True)
+                ok.append(labels.tolist() == case["labels"] and "seconds_all_gather" in stats)
+        out.put(ok)
+    finally:
+        dist.destroy_process_group()
+
+
+def test_compare_matrix_all_gather_on_device_memory():
+    """The RCCL leg of the N > 1 path on the one GPU a test box has: a group of one rank over the "nccl" backend,
+    the collective forced on.  RCCL reads the label block at the address the library hands out
+    (malcs_relmatrix_tiles_device) and the assembly kernel reads what RCCL wrote (malcs_relmatrix_assemble_device)."""
+    import torch.multiprocessing as mp
+    ctx = mp.get_context("spawn")
+    out = ctx.Queue()
+    port = 33500 + np.random.RandomState().randint(0, 2000)
+    proc = ctx.Process(target=_matrix_rccl_rank, args=(port, out))
+    proc.start()
+    ok = out.get(timeout=150)
+    proc.join(timeout=60)
+    assert proc.exitcode == 0
+    assert ok and all(ok)
