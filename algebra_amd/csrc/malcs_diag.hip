@@ -252,6 +252,106 @@ __device__ __forceinline__ void diag_block_dna3(uint32_t (&V)[3], const uint32_t
     V[0] = V0; V[1] = V1; V[2] = V2;
 }
 
+// Three blocks in one statement.  Between two blocks the window moves down one limb; done in registers
+// that means a dozen moves (V, both pattern planes, the text words) next to mask arithmetic for the
+// first / last blocks of a pair.  Inside the fast stretch of a tile (every lane's columns and leaving rows
+// exist, see the kernel) none of that is needed: the three limbs trade ROLES instead of contents -- block A
+// runs with limbs (a, b, c) as (0, 1, 2), block B with (b, c, a), block C with (c, a, b) -- so after three
+// blocks every limb is back in its place.  The limb that leaves banks its zero bits (v_not + v_bcnt),
+// restarts at all ones and takes the pattern planes of the limb that enters (loaded one block ahead into
+// the four result registers, moved over after the wait).  12 instructions per transition instead of 56.
+// Registers as above; limb a = V v20 / P v21, v33; b = v24 / v25, v37; c = v28 / v29, v41.
+#define TG_LA "v20", "v21", "v33"
+#define TG_LB "v24", "v25", "v37"
+#define TG_LC "v28", "v29", "v41"
+#define TG_Ua(U, V, P0, X0) "v_bitop3_b32 " U ", " V ", " P0 ", " X0 " bitop3:0x90\n\t"
+#define TG_Ub(U, P1, X1) "v_bitop3_b32 " U ", " U ", " P1 ", " X1 " bitop3:0x90\n\t"
+#define TG_AD0(S, O, V, U) "v_add_co_u32_e64 " S ", " O ", " V ", " U "\n\t"
+#define TG_ADC(S, O, V, U, I) "v_addc_co_u32_e64 " S ", " O ", " V ", " U ", " I "\n\t"
+#define TG_N(V, U, S) "v_bitop3_b32 " V ", " U ", " S ", " V " bitop3:0xde\n\t"
+// roles: limb 0 works in v22 / v23, limb 1 in v26 / v27, limb 2 in v30 / v31 (U / sum)
+#define TG_STEP_(s, A0, A1, B0, B1, C0, C1, I1, I2, O1, O2, V0, P00, P01, V1, P10, P11, V2, P20, P21)     \
+    DG_BFE(s, A0, A1) TG_Ua("v26", V1, P10, B0) TG_Ua("v30", V2, P20, C0) TG_Ua("v22", V0, P00, A0)       \
+    TG_Ub("v26", P11, B1) TG_Ub("v30", P21, C1) TG_Ub("v22", P01, A1)                                      \
+    TG_ADC("v31", "s[48:49]", V2, "v30", I2) TG_ADC("v27", O2, V1, "v26", I1) TG_AD0("v23", O1, V0, "v22") \
+    TG_N(V2, "v30", "v31") TG_N(V1, "v26", "v27") TG_N(V0, "v22", "v23")
+#define TG_STEP(s, A, B, C, I, O, V0, P00, P01, V1, P10, P11, V2, P20, P21) \
+    TG_STEP_(s, A, B, C, I, O, V0, P00, P01, V1, P10, P11, V2, P20, P21)
+#define TG_FILL0_(s, A0, A1, O1, O2, V0, P00, P01) \
+    DG_BFE(s, A0, A1) TG_Ua("v22", V0, P00, A0) TG_Ub("v22", P01, A1) TG_AD0("v23", O1, V0, "v22") TG_N(V0, "v22", "v23")
+#define TG_FILL0(s, A, O, V0, P00, P01) TG_FILL0_(s, A, O, V0, P00, P01)
+#define TG_FILL1_(s, A0, A1, B0, B1, I1, I2, O1, O2, V0, P00, P01, V1, P10, P11)                           \
+    DG_BFE(s, A0, A1) TG_Ua("v26", V1, P10, B0) TG_Ua("v22", V0, P00, A0) TG_Ub("v26", P11, B1) TG_Ub("v22", P01, A1) \
+    TG_ADC("v27", O2, V1, "v26", I1) TG_AD0("v23", O1, V0, "v22") TG_N(V1, "v26", "v27") TG_N(V0, "v22", "v23")
+#define TG_FILL1(s, A, B, I, O, V0, P00, P01, V1, P10, P11) TG_FILL1_(s, A, B, I, O, V0, P00, P01, V1, P10, P11)
+#define TG_DRAIN1_(B0, B1, C0, C1, I1, I2, O1, O2, V1, P10, P11, V2, P20, P21)                             \
+    TG_Ua("v26", V1, P10, B0) TG_Ua("v30", V2, P20, C0) TG_Ub("v26", P11, B1) TG_Ub("v30", P21, C1)        \
+    TG_ADC("v31", "s[48:49]", V2, "v30", I2) TG_ADC("v27", O2, V1, "v26", I1) TG_N(V2, "v30", "v31") TG_N(V1, "v26", "v27")
+#define TG_DRAIN1(B, C, I, O, V1, P10, P11, V2, P20, P21) TG_DRAIN1_(B, C, I, O, V1, P10, P11, V2, P20, P21)
+#define TG_DRAIN2_(C0, C1, I1, I2, V2, P20, P21) \
+    TG_Ua("v30", V2, P20, C0) TG_Ub("v30", P21, C1) TG_ADC("v31", "s[48:49]", V2, "v30", I2) TG_N(V2, "v30", "v31")
+#define TG_DRAIN2(C, I, V2, P20, P21) TG_DRAIN2_(C, I, V2, P20, P21)
+#define TG_SIX(s0, s1, s2, s3, s4, s5, V0, P00, P01, V1, P10, P11, V2, P20, P21)                            \
+    TG_STEP(s0, DG_X2, DG_X1, DG_X0, DG_CO, DG_CE, V0, P00, P01, V1, P10, P11, V2, P20, P21) TG_STEP(s1, DG_X0, DG_X2, DG_X1, DG_CE, DG_CO, V0, P00, P01, V1, P10, P11, V2, P20, P21) \
+    TG_STEP(s2, DG_X1, DG_X0, DG_X2, DG_CO, DG_CE, V0, P00, P01, V1, P10, P11, V2, P20, P21) TG_STEP(s3, DG_X2, DG_X1, DG_X0, DG_CE, DG_CO, V0, P00, P01, V1, P10, P11, V2, P20, P21) \
+    TG_STEP(s4, DG_X0, DG_X2, DG_X1, DG_CO, DG_CE, V0, P00, P01, V1, P10, P11, V2, P20, P21) TG_STEP(s5, DG_X1, DG_X0, DG_X2, DG_CE, DG_CO, V0, P00, P01, V1, P10, P11, V2, P20, P21)
+#define TG_BLOCK_(V0, P00, P01, V1, P10, P11, V2, P20, P21)                                                 \
+    ".p2align 3\n\ts_nop 0\n\t"                                                                             \
+    TG_FILL0(0, DG_X0, DG_CE, V0, P00, P01) TG_FILL1(1, DG_X1, DG_X0, DG_CE, DG_CO, V0, P00, P01, V1, P10, P11) \
+    TG_SIX(2, 3, 4, 5, 6, 7, V0, P00, P01, V1, P10, P11, V2, P20, P21) TG_SIX(8, 9, 10, 11, 12, 13, V0, P00, P01, V1, P10, P11, V2, P20, P21) TG_SIX(14, 15, 16, 17, 18, 19, V0, P00, P01, V1, P10, P11, V2, P20, P21) \
+    TG_SIX(20, 21, 22, 23, 24, 25, V0, P00, P01, V1, P10, P11, V2, P20, P21) TG_SIX(26, 27, 28, 29, 30, 31, V0, P00, P01, V1, P10, P11, V2, P20, P21)                            \
+    TG_DRAIN1(DG_X1, DG_X0, DG_CO, DG_CE, V1, P10, P11, V2, P20, P21) TG_DRAIN2(DG_X1, DG_CE, V2, P20, P21)
+#define TG_BLOCK(L0, L1, L2) TG_BLOCK_(L0, L1, L2)
+#define TG_LOADS(o0, o1, o2, o3)                                                                            \
+    "global_load_dword %[n0], %[np], off offset:" #o0 "\n\tglobal_load_dword %[n1], %[np], off offset:" #o1 "\n\t" \
+    "global_load_dword %[n2], %[np], off offset:" #o2 "\n\tglobal_load_dword %[n3], %[np], off offset:" #o3 "\n\t"
+// the limb (V, P0, P1) leaves, restarts and takes the planes of the entering limb; the text words follow
+#define TG_BANK_(V, P0, P1) "v_not_b32 v22, " V "\n\tv_bcnt_u32_b32 %[bank], v22, %[bank]\n\t"
+#define TG_BANK_X(V, P0, P1) TG_BANK_(V, P0, P1)
+#define TG_BANK(L) TG_BANK_X(L)
+#define TG_ENTER_(V, P0, P1)                                                                                \
+    "v_mov_b32 " V ", -1\n\ts_waitcnt vmcnt(0)\n\tv_mov_b32 " P0 ", %[n0]\n\tv_mov_b32 " P1 ", %[n1]\n\t"   \
+    "v_mov_b32 v32, %[n2]\n\tv_mov_b32 v36, %[n3]\n\t"
+#define TG_ENTER_X(V, P0, P1) TG_ENTER_(V, P0, P1)
+#define TG_ENTER(L) TG_ENTER_X(L)
+
+// Runs triples of blocks while `more(it)` holds.  On entry and on return nxt holds the rows of block `it`
+// and p points at them; V[2] / P[2] are dead outside (the limb that enters is set up here, the one that
+// has left is restarted by the caller).  The limbs stay in their pinned registers across the loop.
+template <typename More>
+__device__ __forceinline__ void diag_triples_dna3(uint32_t (&V)[3], uint32_t (&P)[3][2], uint32_t &banked,
+                                                  const uint32_t *&p, uint32_t (&nxt)[4], int &it, More more)
+{
+    register uint32_t V0 asm("v20") = V[0], V1 asm("v24") = V[1], V2 asm("v28");
+    register uint32_t P00 asm("v21") = P[0][0], P10 asm("v25") = P[1][0], P20 asm("v29");
+    register uint32_t P01 asm("v33") = P[0][1], P11 asm("v37") = P[1][1], P21 asm("v41");
+    register uint32_t w0 asm("v32"), w1 asm("v36");
+    uint32_t n0 = nxt[0], n1 = nxt[1], n2 = nxt[2], n3 = nxt[3], bank = banked;
+    do {
+        asm volatile(
+            "v_mov_b32 v29, %[n0]\n\tv_mov_b32 v41, %[n1]\n\tv_mov_b32 v32, %[n2]\n\tv_mov_b32 v36, %[n3]\n\tv_mov_b32 v28, -1\n\t"
+            TG_LOADS(1024, 1280, 1536, 1792)
+            TG_BLOCK(TG_LA, TG_LB, TG_LC)
+            TG_BANK(TG_LA) TG_ENTER(TG_LA) TG_LOADS(2048, 2304, 2560, 2816)
+            TG_BLOCK(TG_LB, TG_LC, TG_LA)
+            TG_BANK(TG_LB) TG_ENTER(TG_LB) TG_LOADS(3072, 3328, 3584, 3840)
+            TG_BLOCK(TG_LC, TG_LA, TG_LB)
+            TG_BANK(TG_LC)
+            "s_waitcnt vmcnt(0)"
+            : "+v"(V0), "+v"(V1), "=v"(V2), "+v"(P00), "+v"(P01), "+v"(P10), "+v"(P11), "=v"(P20), "=v"(P21),
+              [w0] "=v"(w0), [w1] "=v"(w1), [bank] "+v"(bank), [n0] "+v"(n0), [n1] "+v"(n1), [n2] "+v"(n2), [n3] "+v"(n3)
+            : [np] "v"(p)
+            : "v22", "v26", "v30", "v23", "v27", "v31", "v35", "v47", "v39", "v51", "v43", "v55",
+              "s40", "s41", "s42", "s43", "s44", "s45", "s46", "s47", "s48", "s49");
+        p += 3 * 4 * 64;
+        it += 3;
+    } while (more(it));
+    V[0] = V0; V[1] = V1;
+    P[0][0] = P00; P[0][1] = P01; P[1][0] = P10; P[1][1] = P11;
+    nxt[0] = n0; nxt[1] = n1; nxt[2] = n2; nxt[3] = n3;
+    banked = bank;
+}
+
 // The same for the other classes: loads the compiler does not see, and a wait statement that every
 // destination passes through before its first use (the loads are unconditional: the buffer is padded).
 template <int J>
@@ -320,7 +420,22 @@ k_llcs_diag(const uint32_t *__restrict__ rows, const uint32_t *__restrict__ tile
     };
     uint32_t banked = 0;
 
-    for (int it = 0; it < iters; it++) {
+    // blocks [plain_lo, plain_hi) of a lane need no masks: all 32 columns exist and so do all rows of the leaving limb
+    int plain_lo = 0, plain_hi = 0x7fffffff;
+    if (pid != 0xffffffffu) {
+        plain_lo = max(c0 < 0 ? 1 : 0, -R0);
+        const int cols = (int)n - c0 - 32;
+        plain_hi = min(cols >= 0 ? cols / 32 + 1 : 0, (int)(m >> 5) - R0);
+    }
+
+    for (int it = 0; it < iters;) {
+        if constexpr (NLW == 3 && NP == 2 && FUSED) {
+            auto plain3 = [&](int i) { return i + 3 <= iters && __builtin_amdgcn_ballot_w64(i < plain_lo || i + 3 > plain_hi) == 0; };
+            if (plain3(it)) {
+                diag_triples_dna3(V, P, banked, p, nxt, it, plain3);
+                continue;
+            }
+        }
         uint32_t w[NP];
 #pragma unroll
         for (int q = 0; q < NP; q++) { P[NLW - 1][q] = nxt[q]; w[q] = nxt[NP + q]; }
@@ -354,6 +469,7 @@ k_llcs_diag(const uint32_t *__restrict__ rows, const uint32_t *__restrict__ tile
 #pragma unroll
             for (int q = 0; q < NP; q++) P[k][q] = P[k + 1][q];
         }
+        it++;
     }
     uint32_t zeros = banked;
 #pragma unroll
