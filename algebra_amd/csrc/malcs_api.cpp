@@ -237,7 +237,8 @@ static int batch_build(malcs_ctx *ctx, const uint8_t *syms, uint64_t n_syms,
 
     MALCS_HIP(hipSetDevice(ctx->device));
     hipStream_t st = ctx->stream;
-    uint8_t *d_syms = nullptr; uint64_t *d_sbo = nullptr; uint32_t *d_sl = nullptr, *d_sko = nullptr;
+    dev_scoped<uint8_t> syms_dev; dev_scoped<uint64_t> sbo_dev; dev_scoped<uint32_t> sl_dev, sko_dev;   // staging of the pack kernel
+    uint8_t *&d_syms = syms_dev.p; uint64_t *&d_sbo = sbo_dev.p; uint32_t *&d_sl = sl_dev.p, *&d_sko = sko_dev.p;
     if (n_pairs) {
         MALCS_HIP(hipMalloc(&b->d_planes, (b->arena_dwords + 4) * sizeof(uint32_t)));
         MALCS_HIP(hipMalloc(&b->d_a_off, n_pairs * 4)); MALCS_HIP(hipMalloc(&b->d_a_len, n_pairs * 4));
@@ -258,7 +259,6 @@ static int batch_build(malcs_ctx *ctx, const uint8_t *syms, uint64_t n_syms,
             if (rc) return rc;
         }
         MALCS_HIP(malcs_sync(st));
-        hipFree(d_syms); hipFree(d_sbo); hipFree(d_sl); hipFree(d_sko);
     }
     return malcs_dist_plan(b);
 }

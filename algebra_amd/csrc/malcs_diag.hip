@@ -565,7 +565,8 @@ int malcs_diag_plan(malcs_batch *b, int nlw, const std::vector<uint32_t> &pairs,
     for (size_t c = 0; c < classes.size(); c++) { first[c] = acc; acc += cap[c]; d.retry[c].first = first[c]; d.retry[c].cap = cap[c]; }
 
     hipStream_t st = b->ctx->stream;
-    uint32_t *d_tile_pid = nullptr, *d_tile_kc = nullptr;
+    dev_scoped<uint32_t> tile_pid_dev, tile_kc_dev;
+    uint32_t *&d_tile_pid = tile_pid_dev.p, *&d_tile_kc = tile_kc_dev.p;
     const size_t ncls = std::max<size_t>(classes.size(), 1);
     MALCS_HIP(hipMalloc(&d.d_rows, ((size_t)row + 2u * b->n_planes) * 64u * sizeof(uint32_t)));   // + one block of padding: the kernel prefetches unconditionally
     MALCS_HIP(hipMalloc(&d.d_tile_off, (n_tiles + 1) * sizeof(uint32_t)));
@@ -593,7 +594,6 @@ int malcs_diag_plan(malcs_batch *b, int nlw, const std::vector<uint32_t> &pairs,
     }
     MALCS_HIP(hipGetLastError());
     MALCS_HIP(malcs_sync(st));           // the host vectors above are locals
-    hipFree(d_tile_pid); hipFree(d_tile_kc);
     d.nlw = nlw; d.T = T; d.n_tiles = n_tiles; d.n_pairs = (uint32_t)pairs.size(); d.window_cells = cells;
     return MALCS_OK;
 }

@@ -526,7 +526,8 @@ int malcs_dist_band(malcs_batch *b, const std::vector<uint32_t> &pairs, int32_t 
         }
         for (size_t i = 0; i < pairs.size(); i++) if (result[i] < 0) { todo.push_back(pairs[i]); slot_of.push_back(i); }
     }
-    uint32_t *d_work = nullptr; int32_t *d_thresh = nullptr, *d_out = nullptr;
+    dev_scoped<uint32_t> work_dev; dev_scoped<int32_t> thresh_dev, out_dev;
+    uint32_t *&d_work = work_dev.p; int32_t *&d_thresh = thresh_dev.p, *&d_out = out_dev.p;
     MALCS_HIP(hipMalloc(&d_work, pairs.size() * 4)); MALCS_HIP(hipMalloc(&d_thresh, pairs.size() * 4)); MALCS_HIP(hipMalloc(&d_out, pairs.size() * 4));
     int rc = MALCS_OK;
     for (int W = 1; W <= wmax && !todo.empty(); W *= 2) {
@@ -575,6 +576,5 @@ int malcs_dist_band(malcs_batch *b, const std::vector<uint32_t> &pairs, int32_t 
         }
         malcs_sync(st);
     }
-    hipFree(d_work); hipFree(d_thresh); hipFree(d_out);
     return rc;
 }

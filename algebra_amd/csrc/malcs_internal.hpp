@@ -18,6 +18,16 @@ void malcs_set_error(const char *fmt, ...);
         }                                                                                     \
     } while (0)
 
+// device memory that is released on every return path of the function that holds it
+template <typename T> struct dev_scoped {
+    T *p = nullptr;
+    dev_scoped() = default;
+    dev_scoped(const dev_scoped &) = delete;
+    dev_scoped &operator=(const dev_scoped &) = delete;
+    ~dev_scoped() { if (p) (void)hipFree(p); }
+};
+
+
 // A device-to-host copy that went through the staging buffer: lands in `dst` at the next malcs_sync.
 struct staged_copy { void *dst; const void *src; size_t bytes; };
 
