@@ -209,6 +209,21 @@ def test_edit_distance_window_class(native, nlw, nsym, monkeypatch):
         assert (ref > 32 * nlw - 32).sum() > 50 and (ref <= 32 * nlw - 32).sum() > 50
 
 
+def test_edit_distance_window_class_mixed_tiles(native):
+    """Tiles of the default window class whose lanes differ in length, length difference and divergence: the
+    three-block statement of the plain stretch, the masked first / last blocks and the retry list in one batch."""
+    from oracle import oracle as O
+    data = gen.window_mix(6000, seed=11)
+    batch = native.Batch(native.default_context(), *data, n_symbols=4)
+    info = batch.plan_info()
+    got = batch.distances()
+    batch.close()
+    ref = O.edit_distance_batch(*data)
+    assert info["window_pairs"] > 5000 and info["window_limbs"] == 3
+    assert (ref > info["window_threshold"]).sum() > 500
+    assert np.array_equal(got, ref)
+
+
 def test_empty_batch_and_bad_arguments(native):
     import algebra_amd
     assert algebra_amd.edit_distance_batch([]).tolist() == []
