@@ -613,7 +613,8 @@ static int graph_batch(malcs_batch *b, const int64_t *shift, const int64_t *max_
                     hi = (int32_t)((D + delta) / 2 + 1);
                     groups = (int32_t)(((int64_t)hi - lo) >> logG) + 2;
                 }
-                const uint64_t need = ((uint64_t)n + 1ull) * (uint64_t)groups * 2ull * NL;
+                // columns 0 ... n, one record per group in the band; resident windows index by systolic step (column + group)
+                const uint64_t need = ((uint64_t)n + 1ull + (lc.band ? 0ull : (uint64_t)groups)) * (uint64_t)groups * 2ull * NL;
                 if (!work.empty() && used + need > budget_dwords) break;
                 if (need > budget_dwords) {
                     malcs_set_error("pair %u needs %llu MiB of tie-bit rows; device has %llu MiB free", pid,

@@ -200,7 +200,10 @@ k_lcs_forward(const uint32_t *__restrict__ planes,
                 const int ulo = band_ulo(c, kmax, logG);
                 const int su = (int)u - ulo;
                 if (su >= 0 && su < RW && (int)u <= band_uhi(c, kmin, logG, NG)) {
-                    uint32_t *rec = base + ((uint64_t)c * (uint64_t)RW + (uint64_t)su) * (2u * NL);
+                    // resident windows (all groups, su == u): records in the order of the systolic steps, so that
+                    // what the lanes of a pair store in one step is one contiguous stretch (step c + u, group u)
+                    const uint64_t row = BAND ? (uint64_t)c : (uint64_t)(c + su);
+                    uint32_t *rec = base + (row * (uint64_t)RW + (uint64_t)su) * (2u * NL);
                     limb_io<NL>::store_rev(rec, Vold);
                     if (!last) limb_io<NL>::store_rev(rec + NL, Hc);
                 }
@@ -347,7 +350,8 @@ k_lcs_reach(const uint32_t *__restrict__ planes,
 #pragma unroll
             for (int k = 0; k < NL; k++) { T[k] = 0u; H[k] = ~0u; }
             if (active) {
-                const uint32_t *rec = base_ptr + ((uint64_t)c * (uint64_t)RW + (uint64_t)su) * (2u * NL);
+                const uint64_t row = BAND ? (uint64_t)c : (uint64_t)(c + su);
+                const uint32_t *rec = base_ptr + (row * (uint64_t)RW + (uint64_t)su) * (2u * NL);
                 limb_io<NL>::load(rec, T);
                 if (normal) limb_io<NL>::load(rec + NL, H);
             }
