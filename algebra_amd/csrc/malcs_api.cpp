@@ -260,7 +260,10 @@ static int batch_build(malcs_ctx *ctx, const uint8_t *syms, uint64_t n_syms,
         }
         MALCS_HIP(malcs_sync(st));
     }
-    return malcs_dist_plan(b);
+    b->raw_syms = syms; b->raw_a_off = a_off; b->raw_b_off = b_off;
+    const int rc = malcs_dist_plan(b);
+    b->raw_syms = nullptr; b->raw_a_off = b->raw_b_off = nullptr;
+    return rc;
 }
 
 int malcs_batch_create(malcs_ctx *ctx, const uint8_t *syms, uint64_t n_syms,

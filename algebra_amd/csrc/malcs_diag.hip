@@ -46,8 +46,8 @@ __host__ __device__ inline int diag_first_limb(int kmax) { return -((kmax + 31) 
 template <int NP>
 __global__ void __launch_bounds__(64)
 k_diag_layout(const uint32_t *__restrict__ planes,
-              const uint32_t *__restrict__ a_off, const uint32_t *__restrict__ a_len,
-              const uint32_t *__restrict__ b_off, const uint32_t *__restrict__ b_len,
+              const uint32_t *__restrict__ tile_po, const uint32_t *__restrict__ tile_to,
+              const uint32_t *__restrict__ tile_m, const uint32_t *__restrict__ tile_n,
               const uint32_t *__restrict__ tile_pid, const uint32_t *__restrict__ tile_kc,
               const uint32_t *__restrict__ tile_off, const uint32_t *__restrict__ tile_iters,
               int nlw, uint32_t *__restrict__ rows)
@@ -55,14 +55,11 @@ k_diag_layout(const uint32_t *__restrict__ planes,
     const uint32_t tile = blockIdx.y, r = blockIdx.x, lane = threadIdx.x;
     const uint32_t iters = tile_iters[tile];
     if (r >= (uint32_t)(nlw - 1) + iters) return;
-    const uint32_t pid = tile_pid[tile * 64u + lane];
-    const uint32_t kc = tile_kc[tile * 64u + lane];
-    uint32_t m = 0, n = 0, po = 0, to = 0;
-    if (pid != 0xffffffffu) {
-        const uint32_t la = a_len[pid], lb = b_len[pid];
-        if (la <= lb) { m = la; n = lb; po = a_off[pid]; to = b_off[pid]; }
-        else          { m = lb; n = la; po = b_off[pid]; to = a_off[pid]; }
-    }
+    const uint32_t slot = tile * 64u + lane;
+    const uint32_t pid = tile_pid[slot];
+    const uint32_t kc = tile_kc[slot];
+    // pattern (the shorter sequence) and text of the slot, common ends already cut off by the plan
+    const uint32_t m = tile_m[slot], n = tile_n[slot], po = tile_po[slot], to = tile_to[slot];
     uint32_t *out = rows + (size_t)tile_off[tile] * 64u + lane;
     if (r == 0) { out[0] = pid; out[64] = m; out[128] = n; out[192] = kc; }
     const int kmax = (int)(kc & 0xffffu);
@@ -525,29 +522,84 @@ int malcs_diag_plan(malcs_batch *b, int nlw, const std::vector<uint32_t> &pairs,
         return MALCS_ERR_INTERNAL;
     }
     const int T = malcs_diag_threshold(nlw);
-    struct item { uint32_t pid, kc, iters; };
+    // Common ends do not change the distance (the reference's sweep slides through them in one snake, LCSgraph.from_sequence
+    // cuts them off with trim(), lcs_graph.py:231-235): whole blocks of 32 symbols in front and any number of symbols at the
+    // end are left out of the window, as long as enough rows for the window class remain.  Needs the caller's symbols, so
+    // only at batch creation; MALCS_DIAG_TRIM=0 switches it off.
+    const bool trim = b->raw_syms && !(getenv("MALCS_DIAG_TRIM") && atoi(getenv("MALCS_DIAG_TRIM")) == 0);
+    const uint32_t min_rows = 32u * (2u * (uint32_t)nlw + 2u);
+    const uint32_t NP = (uint32_t)b->n_planes;
+    struct item { uint32_t pid, kc, iters, po, to, m, n; };
     std::vector<item> items(pairs.size());
     uint64_t cells = 0;
     for (size_t i = 0; i < pairs.size(); i++) {
         const uint32_t pid = pairs[i];
-        const uint32_t m = std::min(b->a_len[pid], b->b_len[pid]), n = std::max(b->a_len[pid], b->b_len[pid]);
+        const bool a_short = b->a_len[pid] <= b->b_len[pid];
+        uint32_t m = a_short ? b->a_len[pid] : b->b_len[pid], n = a_short ? b->b_len[pid] : b->a_len[pid];
+        uint32_t po = a_short ? b->a_off[pid] : b->b_off[pid], to = a_short ? b->b_off[pid] : b->a_off[pid];
         const int delta = (int)(n - m);
         if (delta > T || n == 0) { malcs_set_error("pair %u does not fit the window class", pid); return MALCS_ERR_INTERNAL; }
+        if (trim && m > min_rows) {
+            const uint8_t *x = b->raw_syms + (a_short ? b->raw_a_off[pid] : b->raw_b_off[pid]);     // pattern, m symbols
+            const uint8_t *y = b->raw_syms + (a_short ? b->raw_b_off[pid] : b->raw_a_off[pid]);     // text, n symbols
+            const uint32_t room = m - min_rows;
+            uint32_t pre = 0;
+            while (pre < room && x[pre] == y[pre]) pre++;
+            pre &= ~31u;
+            uint32_t suf = 0;
+            while (suf < room - pre && x[m - 1 - suf] == y[n - 1 - suf]) suf++;
+            po += (pre >> 5) * NP; to += (pre >> 5) * NP;
+            m -= pre + suf; n -= pre + suf;
+        }
         const int kmax = delta + (T - delta) / 2;
         const int c0 = 32 * diag_first_limb(kmax) + kmax;
-        items[i] = {pid, (uint32_t)kmax | ((uint32_t)retry_class[i] << 16), (uint32_t)(((int)n - 1 - c0) / 32 + 1)};
+        items[i] = {pid, (uint32_t)kmax | ((uint32_t)retry_class[i] << 16), (uint32_t)(((int)n - 1 - c0) / 32 + 1), po, to, m, n};
         cells += (uint64_t)(32 * nlw) * n;
     }
     std::stable_sort(items.begin(), items.end(), [](const item &x, const item &y) { return x.iters < y.iters; });
     const uint32_t n_tiles = (uint32_t)((items.size() + 63) / 64);
     std::vector<uint32_t> tile_pid((size_t)n_tiles * 64, 0xffffffffu), tile_kc((size_t)n_tiles * 64, 0u);
+    std::vector<uint32_t> tile_seq((size_t)n_tiles * 64 * 4, 0u);          // po, to, m, n of every slot (four arrays back to back)
+    const size_t slots = (size_t)n_tiles * 64;
     std::vector<uint32_t> tile_off(n_tiles + 1), tile_iters(n_tiles);
+    // Which tile runs as which workgroup.  All workgroups of a launch are resident at once, and the dispatcher deals
+    // them round-robin: workgroups p and p + S share a SIMD (S = SIMDs of the device; tools/wave_placement.hip: every one
+    // of the 539 two-wave SIMDs of a 1 563-wave launch holds indices 1 024 apart).  A launch ends with its most loaded
+    // SIMD, so the tiles (sorted by length above) are dealt longest first to the SIMD with the least work so far among
+    // those with a free slot, SIMDs with fewer slots first: at C2 the 485 SIMDs with one wave get the longest tiles and
+    // the others a long and a short one each.
+    std::vector<uint32_t> tile_at(n_tiles);                    // workgroup index -> tile (in sorted order)
+    {
+        const uint32_t S = std::max(1, b->ctx->prop.multiProcessorCount) * 4u;
+        struct simd_load { uint64_t load; uint32_t slots, used, idx; };
+        auto worse = [](const simd_load &x, const simd_load &y) {   // priority queue: top = least load, then fewest slots
+            if (x.load != y.load) return x.load > y.load;
+            if (x.slots != y.slots) return x.slots > y.slots;
+            return x.idx > y.idx;
+        };
+        std::vector<simd_load> heap;
+        for (uint32_t i = 0; i < std::min(S, n_tiles); i++) heap.push_back({0, (n_tiles - i + S - 1) / S, 0, i});
+        std::make_heap(heap.begin(), heap.end(), worse);
+        for (uint32_t r = 0; r < n_tiles; r++) {
+            const uint32_t j = n_tiles - 1 - r;                // longest first
+            uint32_t it = 1;
+            for (size_t i = (size_t)j * 64; i < std::min(items.size(), (size_t)(j + 1) * 64); i++) it = std::max(it, items[i].iters);
+            std::pop_heap(heap.begin(), heap.end(), worse);
+            simd_load &top = heap.back();
+            tile_at[top.idx + top.used * S] = j;
+            top.used++; top.load += it;
+            if (top.used == top.slots) heap.pop_back(); else std::push_heap(heap.begin(), heap.end(), worse);
+        }
+    }
     uint64_t row = 0;
     uint32_t max_rows = 0;
     for (uint32_t t = 0; t < n_tiles; t++) {
         uint32_t it = 1;
-        for (size_t i = (size_t)t * 64; i < std::min(items.size(), (size_t)(t + 1) * 64); i++) {
-            tile_pid[i] = items[i].pid; tile_kc[i] = items[i].kc; it = std::max(it, items[i].iters);
+        const size_t j0 = (size_t)tile_at[t] * 64, s0 = (size_t)t * 64;
+        for (size_t i = j0; i < std::min(items.size(), j0 + 64); i++) {
+            const size_t k = s0 + (i - j0);
+            tile_pid[k] = items[i].pid; tile_kc[k] = items[i].kc; it = std::max(it, items[i].iters);
+            tile_seq[k] = items[i].po; tile_seq[slots + k] = items[i].to; tile_seq[2 * slots + k] = items[i].m; tile_seq[3 * slots + k] = items[i].n;
         }
         tile_off[t] = (uint32_t)row; tile_iters[t] = it;
         const uint32_t r = (uint32_t)(nlw - 1) + it;
@@ -565,8 +617,8 @@ int malcs_diag_plan(malcs_batch *b, int nlw, const std::vector<uint32_t> &pairs,
     for (size_t c = 0; c < classes.size(); c++) { first[c] = acc; acc += cap[c]; d.retry[c].first = first[c]; d.retry[c].cap = cap[c]; }
 
     hipStream_t st = b->ctx->stream;
-    dev_scoped<uint32_t> tile_pid_dev, tile_kc_dev;
-    uint32_t *&d_tile_pid = tile_pid_dev.p, *&d_tile_kc = tile_kc_dev.p;
+    dev_scoped<uint32_t> tile_pid_dev, tile_kc_dev, tile_seq_dev;
+    uint32_t *&d_tile_pid = tile_pid_dev.p, *&d_tile_kc = tile_kc_dev.p, *&d_tile_seq = tile_seq_dev.p;
     const size_t ncls = std::max<size_t>(classes.size(), 1);
     MALCS_HIP(hipMalloc(&d.d_rows, ((size_t)row + 2u * b->n_planes) * 64u * sizeof(uint32_t)));   // + one block of padding: the kernel prefetches unconditionally
     MALCS_HIP(hipMalloc(&d.d_tile_off, (n_tiles + 1) * sizeof(uint32_t)));
@@ -577,10 +629,12 @@ int malcs_diag_plan(malcs_batch *b, int nlw, const std::vector<uint32_t> &pairs,
     MALCS_HIP(hipMalloc(&d.d_retry_count, 2 * ncls * sizeof(uint32_t)));   // two sets, used by alternate launches
     MALCS_HIP(hipMalloc(&d_tile_pid, tile_pid.size() * sizeof(uint32_t)));
     MALCS_HIP(hipMalloc(&d_tile_kc, tile_kc.size() * sizeof(uint32_t)));
+    MALCS_HIP(hipMalloc(&d_tile_seq, tile_seq.size() * sizeof(uint32_t)));
     MALCS_HIP(malcs_h2d(st, d.d_tile_off, tile_off.data(), (n_tiles + 1) * sizeof(uint32_t)));
     MALCS_HIP(malcs_h2d(st, d.d_tile_iters, tile_iters.data(), n_tiles * sizeof(uint32_t)));
     MALCS_HIP(malcs_h2d(st, d_tile_pid, tile_pid.data(), tile_pid.size() * sizeof(uint32_t)));
     MALCS_HIP(malcs_h2d(st, d_tile_kc, tile_kc.data(), tile_kc.size() * sizeof(uint32_t)));
+    MALCS_HIP(malcs_h2d(st, d_tile_seq, tile_seq.data(), tile_seq.size() * sizeof(uint32_t)));
     if (!classes.empty()) {
         MALCS_HIP(malcs_h2d(st, d.d_retry_first, first.data(), classes.size() * sizeof(uint32_t)));
         MALCS_HIP(malcs_h2d(st, d.d_retry_cap, cap.data(), classes.size() * sizeof(uint32_t)));
@@ -588,9 +642,9 @@ int malcs_diag_plan(malcs_batch *b, int nlw, const std::vector<uint32_t> &pairs,
     MALCS_HIP(hipMemsetAsync(d.d_retry_count, 0, 2 * ncls * sizeof(uint32_t), st));
     const dim3 grid(max_rows, n_tiles), block(64);
     switch (b->n_planes) {
-    case 2: hipLaunchKernelGGL(k_diag_layout<2>, grid, block, 0, st, b->d_planes, b->d_a_off, b->d_a_len, b->d_b_off, b->d_b_len, d_tile_pid, d_tile_kc, d.d_tile_off, d.d_tile_iters, nlw, d.d_rows); break;
-    case 3: hipLaunchKernelGGL(k_diag_layout<3>, grid, block, 0, st, b->d_planes, b->d_a_off, b->d_a_len, b->d_b_off, b->d_b_len, d_tile_pid, d_tile_kc, d.d_tile_off, d.d_tile_iters, nlw, d.d_rows); break;
-    case 4: hipLaunchKernelGGL(k_diag_layout<4>, grid, block, 0, st, b->d_planes, b->d_a_off, b->d_a_len, b->d_b_off, b->d_b_len, d_tile_pid, d_tile_kc, d.d_tile_off, d.d_tile_iters, nlw, d.d_rows); break;
+    case 2: hipLaunchKernelGGL(k_diag_layout<2>, grid, block, 0, st, b->d_planes, d_tile_seq, d_tile_seq + slots, d_tile_seq + 2 * slots, d_tile_seq + 3 * slots, d_tile_pid, d_tile_kc, d.d_tile_off, d.d_tile_iters, nlw, d.d_rows); break;
+    case 3: hipLaunchKernelGGL(k_diag_layout<3>, grid, block, 0, st, b->d_planes, d_tile_seq, d_tile_seq + slots, d_tile_seq + 2 * slots, d_tile_seq + 3 * slots, d_tile_pid, d_tile_kc, d.d_tile_off, d.d_tile_iters, nlw, d.d_rows); break;
+    case 4: hipLaunchKernelGGL(k_diag_layout<4>, grid, block, 0, st, b->d_planes, d_tile_seq, d_tile_seq + slots, d_tile_seq + 2 * slots, d_tile_seq + 3 * slots, d_tile_pid, d_tile_kc, d.d_tile_off, d.d_tile_iters, nlw, d.d_rows); break;
     }
     MALCS_HIP(hipGetLastError());
     MALCS_HIP(malcs_sync(st));           // the host vectors above are locals

@@ -91,6 +91,9 @@ struct malcs_batch {
     std::vector<dist_bucket> dist_buckets;
     std::vector<uint32_t> band_pairs;    // pairs too long for a resident pattern: sliding-window kernel
     diag_plan diag;
+    // the caller's buffers, valid only while malcs_batch_create runs (the plan looks for common ends of similar pairs)
+    const uint8_t *raw_syms = nullptr;
+    const uint64_t *raw_a_off = nullptr, *raw_b_off = nullptr;
     uint64_t full_cells = 0;             // sum of m * n over the batch
     uint64_t arena_dwords = 0;
     uint32_t max_len = 0;
