@@ -47,7 +47,7 @@ template <int NP>
 __global__ void __launch_bounds__(64)
 k_diag_layout(const uint32_t *__restrict__ planes,
               const uint32_t *__restrict__ tile_po, const uint32_t *__restrict__ tile_to,
-              const uint32_t *__restrict__ tile_m, const uint32_t *__restrict__ tile_n,
+              const uint32_t *__restrict__ tile_m, const uint32_t *__restrict__ tile_n, const uint32_t *__restrict__ tile_q,
               const uint32_t *__restrict__ tile_pid, const uint32_t *__restrict__ tile_kc,
               const uint32_t *__restrict__ tile_off, const uint32_t *__restrict__ tile_iters,
               int nlw, uint32_t *__restrict__ rows)
@@ -58,15 +58,22 @@ k_diag_layout(const uint32_t *__restrict__ planes,
     const uint32_t slot = tile * 64u + lane;
     const uint32_t pid = tile_pid[slot];
     const uint32_t kc = tile_kc[slot];
-    // pattern (the shorter sequence) and text of the slot, common ends already cut off by the plan
-    const uint32_t m = tile_m[slot], n = tile_n[slot], po = tile_po[slot], to = tile_to[slot];
+    // pattern (the shorter sequence) and text of the slot, common ends already cut off by the plan: both start q symbols
+    // (0 ... 31) into the block at po / to and have m / n symbols from there
+    const uint32_t m = tile_m[slot], n = tile_n[slot], po = tile_po[slot], to = tile_to[slot], q = tile_q[slot];
     uint32_t *out = rows + (size_t)tile_off[tile] * 64u + lane;
     if (r == 0) { out[0] = pid; out[64] = m; out[128] = n; out[192] = kc; }
     const int kmax = (int)(kc & 0xffffu);
     const int R0 = diag_first_limb(kmax);
-    const int pblk = (int)((m + 31u) >> 5), tblk = (int)((n + 31u) >> 5);
+    const int pblk = (int)((m + 31u) >> 5), tblk = (int)((n + q + 31u) >> 5);
     out += META_ROWS * 64;
-    auto limb = [&](int g, int p) -> uint32_t { return (g >= 0 && g < pblk) ? planes[po + (uint32_t)g * NP + p] : 0u; };
+    // 32 rows from row 32 g of the pattern as cut; the word after a sequence's last one is its neighbour's or the
+    // arena's padding (rows beyond m never matter)
+    auto limb = [&](int g, int p) -> uint32_t {
+        if (g < 0 || g >= pblk) return 0u;
+        const uint32_t lo = planes[po + (uint32_t)g * NP + p];
+        return q ? ((lo >> q) | (planes[po + (uint32_t)(g + 1) * NP + p] << (32u - q))) : lo;
+    };
     auto text = [&](int blk, int p) -> uint32_t { return (blk >= 0 && blk < tblk) ? planes[to + (uint32_t)blk * NP + p] : 0u; };
     if (r < (uint32_t)(nlw - 1)) {
 #pragma unroll
@@ -75,7 +82,7 @@ k_diag_layout(const uint32_t *__restrict__ planes,
     }
     const int it = (int)r - (nlw - 1);
     out += (size_t)(nlw - 1) * NP * 64u + (size_t)it * 2u * NP * 64u;
-    const int c = 32 * (R0 + it) + kmax;           // first column of this block, may be negative in block 0
+    const int c = 32 * (R0 + it) + kmax + (int)q;  // first column of this block in the stored text, may be negative in block 0
     const int blk = c >> 5;                        // arithmetic shift = floor
     const uint32_t sh = (uint32_t)c & 31u;
 #pragma unroll
@@ -523,13 +530,13 @@ int malcs_diag_plan(malcs_batch *b, int nlw, const std::vector<uint32_t> &pairs,
     }
     const int T = malcs_diag_threshold(nlw);
     // Common ends do not change the distance (the reference's sweep slides through them in one snake, LCSgraph.from_sequence
-    // cuts them off with trim(), lcs_graph.py:231-235): whole blocks of 32 symbols in front and any number of symbols at the
-    // end are left out of the window, as long as enough rows for the window class remain.  Needs the caller's symbols, so
+    // cuts them off with trim(), lcs_graph.py:231-235): they are left out of the window (the layout kernel shifts pattern and
+    // text by what is cut in front), as long as enough rows for the window class remain.  Needs the caller's symbols, so
     // only at batch creation; MALCS_DIAG_TRIM=0 switches it off.
     const bool trim = b->raw_syms && !(getenv("MALCS_DIAG_TRIM") && atoi(getenv("MALCS_DIAG_TRIM")) == 0);
     const uint32_t min_rows = 32u * (2u * (uint32_t)nlw + 2u);
     const uint32_t NP = (uint32_t)b->n_planes;
-    struct item { uint32_t pid, kc, iters, po, to, m, n; };
+    struct item { uint32_t pid, kc, iters, po, to, m, n, q; };
     std::vector<item> items(pairs.size());
     uint64_t cells = 0;
     for (size_t i = 0; i < pairs.size(); i++) {
@@ -537,6 +544,7 @@ int malcs_diag_plan(malcs_batch *b, int nlw, const std::vector<uint32_t> &pairs,
         const bool a_short = b->a_len[pid] <= b->b_len[pid];
         uint32_t m = a_short ? b->a_len[pid] : b->b_len[pid], n = a_short ? b->b_len[pid] : b->a_len[pid];
         uint32_t po = a_short ? b->a_off[pid] : b->b_off[pid], to = a_short ? b->b_off[pid] : b->a_off[pid];
+        uint32_t q = 0;
         const int delta = (int)(n - m);
         if (delta > T || n == 0) { malcs_set_error("pair %u does not fit the window class", pid); return MALCS_ERR_INTERNAL; }
         if (trim && m > min_rows) {
@@ -545,21 +553,20 @@ int malcs_diag_plan(malcs_batch *b, int nlw, const std::vector<uint32_t> &pairs,
             const uint32_t room = m - min_rows;
             uint32_t pre = 0;
             while (pre < room && x[pre] == y[pre]) pre++;
-            pre &= ~31u;
             uint32_t suf = 0;
             while (suf < room - pre && x[m - 1 - suf] == y[n - 1 - suf]) suf++;
-            po += (pre >> 5) * NP; to += (pre >> 5) * NP;
+            po += (pre >> 5) * NP; to += (pre >> 5) * NP; q = pre & 31u;
             m -= pre + suf; n -= pre + suf;
         }
         const int kmax = delta + (T - delta) / 2;
         const int c0 = 32 * diag_first_limb(kmax) + kmax;
-        items[i] = {pid, (uint32_t)kmax | ((uint32_t)retry_class[i] << 16), (uint32_t)(((int)n - 1 - c0) / 32 + 1), po, to, m, n};
+        items[i] = {pid, (uint32_t)kmax | ((uint32_t)retry_class[i] << 16), (uint32_t)(((int)n - 1 - c0) / 32 + 1), po, to, m, n, q};
         cells += (uint64_t)(32 * nlw) * n;
     }
     std::stable_sort(items.begin(), items.end(), [](const item &x, const item &y) { return x.iters < y.iters; });
     const uint32_t n_tiles = (uint32_t)((items.size() + 63) / 64);
     std::vector<uint32_t> tile_pid((size_t)n_tiles * 64, 0xffffffffu), tile_kc((size_t)n_tiles * 64, 0u);
-    std::vector<uint32_t> tile_seq((size_t)n_tiles * 64 * 4, 0u);          // po, to, m, n of every slot (four arrays back to back)
+    std::vector<uint32_t> tile_seq((size_t)n_tiles * 64 * 5, 0u);          // po, to, m, n, q of every slot (five arrays back to back)
     const size_t slots = (size_t)n_tiles * 64;
     std::vector<uint32_t> tile_off(n_tiles + 1), tile_iters(n_tiles);
     // Which tile runs as which workgroup.  All workgroups of a launch are resident at once, and the dispatcher deals
@@ -599,7 +606,7 @@ int malcs_diag_plan(malcs_batch *b, int nlw, const std::vector<uint32_t> &pairs,
         for (size_t i = j0; i < std::min(items.size(), j0 + 64); i++) {
             const size_t k = s0 + (i - j0);
             tile_pid[k] = items[i].pid; tile_kc[k] = items[i].kc; it = std::max(it, items[i].iters);
-            tile_seq[k] = items[i].po; tile_seq[slots + k] = items[i].to; tile_seq[2 * slots + k] = items[i].m; tile_seq[3 * slots + k] = items[i].n;
+            tile_seq[k] = items[i].po; tile_seq[slots + k] = items[i].to; tile_seq[2 * slots + k] = items[i].m; tile_seq[3 * slots + k] = items[i].n; tile_seq[4 * slots + k] = items[i].q;
         }
         tile_off[t] = (uint32_t)row; tile_iters[t] = it;
         const uint32_t r = (uint32_t)(nlw - 1) + it;
@@ -642,9 +649,9 @@ int malcs_diag_plan(malcs_batch *b, int nlw, const std::vector<uint32_t> &pairs,
     MALCS_HIP(hipMemsetAsync(d.d_retry_count, 0, 2 * ncls * sizeof(uint32_t), st));
     const dim3 grid(max_rows, n_tiles), block(64);
     switch (b->n_planes) {
-    case 2: hipLaunchKernelGGL(k_diag_layout<2>, grid, block, 0, st, b->d_planes, d_tile_seq, d_tile_seq + slots, d_tile_seq + 2 * slots, d_tile_seq + 3 * slots, d_tile_pid, d_tile_kc, d.d_tile_off, d.d_tile_iters, nlw, d.d_rows); break;
-    case 3: hipLaunchKernelGGL(k_diag_layout<3>, grid, block, 0, st, b->d_planes, d_tile_seq, d_tile_seq + slots, d_tile_seq + 2 * slots, d_tile_seq + 3 * slots, d_tile_pid, d_tile_kc, d.d_tile_off, d.d_tile_iters, nlw, d.d_rows); break;
-    case 4: hipLaunchKernelGGL(k_diag_layout<4>, grid, block, 0, st, b->d_planes, d_tile_seq, d_tile_seq + slots, d_tile_seq + 2 * slots, d_tile_seq + 3 * slots, d_tile_pid, d_tile_kc, d.d_tile_off, d.d_tile_iters, nlw, d.d_rows); break;
+    case 2: hipLaunchKernelGGL(k_diag_layout<2>, grid, block, 0, st, b->d_planes, d_tile_seq, d_tile_seq + slots, d_tile_seq + 2 * slots, d_tile_seq + 3 * slots, d_tile_seq + 4 * slots, d_tile_pid, d_tile_kc, d.d_tile_off, d.d_tile_iters, nlw, d.d_rows); break;
+    case 3: hipLaunchKernelGGL(k_diag_layout<3>, grid, block, 0, st, b->d_planes, d_tile_seq, d_tile_seq + slots, d_tile_seq + 2 * slots, d_tile_seq + 3 * slots, d_tile_seq + 4 * slots, d_tile_pid, d_tile_kc, d.d_tile_off, d.d_tile_iters, nlw, d.d_rows); break;
+    case 4: hipLaunchKernelGGL(k_diag_layout<4>, grid, block, 0, st, b->d_planes, d_tile_seq, d_tile_seq + slots, d_tile_seq + 2 * slots, d_tile_seq + 3 * slots, d_tile_seq + 4 * slots, d_tile_pid, d_tile_kc, d.d_tile_off, d.d_tile_iters, nlw, d.d_rows); break;
     }
     MALCS_HIP(hipGetLastError());
     MALCS_HIP(malcs_sync(st));           // the host vectors above are locals
