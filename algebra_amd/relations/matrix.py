@@ -146,12 +146,18 @@ def compare_matrix(reference, graphs, tile=256, group=None, distance_fn=None, st
         if world > 1 or gather_always:
             import torch
             backend = dist.get_backend(group)
+            send = None
             if backend == "nccl" and hasattr(tiles, "tiles_device"):
                 # RCCL reads this rank's block where the kernels wrote it and writes the gathered blocks where
-                # the assembly kernel reads them: no host staging
+                # the assembly kernel reads them: no host staging.  (Every rank takes the same branch: wrapping the
+                # library's memory either works in this build of torch or it does not.)
                 address, nbytes = tiles.tiles_device()
                 device = torch.device("cuda", torch.cuda.current_device())
-                send = torch.as_tensor(_DeviceBytes(address, nbytes), device=device)
+                try:
+                    send = torch.as_tensor(_DeviceBytes(address, nbytes), device=device)
+                except (TypeError, RuntimeError, ValueError):
+                    send = None
+            if send is not None:
                 recv = torch.empty(world * nbytes, dtype=torch.uint8, device=device)
                 dist.all_gather_into_tensor(recv, send, group=group)
                 torch.cuda.current_stream(device).synchronize()
