@@ -241,7 +241,8 @@ def main():
 
     # dominant kernel: HIP events on the library's stream around `steps` launches of that kernel alone.
     # Its work is priced on the cells it computes: the window class evaluates 32 * limbs rows of every
-    # column, not the whole matrix (the full-matrix-equivalent figure is `value`, as the metric says).
+    # column between the common ends of a pair, not the whole matrix (the full-matrix-equivalent figure is
+    # `value`, as the metric says).
     plan = batch.plan_info()
     step_ms = batch.time_distances(args.steps) / args.steps
     kernel_ms = batch.time_dominant_kernel(args.steps) / args.steps
@@ -249,7 +250,7 @@ def main():
         kernel_cells = float(plan["window_cells"])
         kernel_name = f"k_llcs_diag<{plan['window_limbs']},2,true>"
         algorithmic = (f"{OPS_PER_CELL} lane-op/cell x {kernel_cells:.4g} window cells/launch "
-                       f"({32 * plan['window_limbs']} rows x text length, {plan['window_pairs']} pairs; "
+                       f"({32 * plan['window_limbs']} rows x text length without the pair's common ends, {plan['window_pairs']} pairs; "
                        f"{cells:.4g} full-matrix-equivalent cells)")
     else:
         kernel_cells = cells
