@@ -6,7 +6,9 @@
 // counterpart: an alignment of cost <= T stays on diagonals k = col - row in
 // [-(T - delta)/2, delta + (T - delta)/2] (delta = n - m >= 0), so of every column only
 // T + 1 rows matter.  Rows are handled in limbs of 32; a window of NLW limbs that moves down one limb
-// per block of 32 columns covers all of them when T = 32 * NLW - 32.
+// per block of 32 columns covers all of them when T = 32 * NLW - 32.  The window is anchored on the columns:
+// block i is columns [32 i, 32 i + 32) of the text and rows [32 i - kmax, 32 i - kmax + 32 NLW) of the pattern
+// (kmax = the band's top diagonal, per pair), so every block of a pair but its last has all 32 columns.
 //
 //   * one LANE per pair, 64 pairs per wave, no cross-lane traffic at all: the window's limbs live in
 //     VGPRs (state V, pattern bit planes P), the carry chain of a column runs through the lane's own
@@ -18,12 +20,13 @@
 //     (then no optimal alignment leaves the band);
 //   * pairs with D' > T are appended to a device-side list per full-matrix launch class and redone
 //     by k_llcs_bitpar_list (malcs_dist.hip) in the same launch sequence, no host round trip;
-//   * data layout: at plan time the pairs of the class are sorted by length and cut into tiles of 64;
-//     k_diag_layout writes, per tile, rows of 64 dwords (one per lane): 4 meta rows, the NLW-1 limbs
-//     the window starts with, then per block of columns the entering pattern limb and the 32 text
-//     bits of that block, already shifted to the lane's own diagonal offset.  The main loop therefore
-//     reads 2 * NP fully coalesced rows (1 KB for DNA) per 32 columns and wave and does no address
-//     arithmetic or funnel shifts of its own.
+//   * data layout: at plan time the common ends of every pair are cut off (they do not change the distance),
+//     the pairs of the class are sorted by what is left and cut into tiles of 64, and the tiles are dealt to
+//     SIMDs by length (malcs_diag_plan); k_diag_layout writes, per tile, rows of 64 dwords (one per lane):
+//     4 meta rows, the NLW-1 limbs the window starts with, then per block of columns the entering pattern
+//     limb, already shifted to the lane's own diagonal offset, and the 32 text bits of that block.  The main
+//     loop therefore reads 2 * NP fully coalesced rows (1 KB for DNA) per 32 columns and wave and does no
+//     address arithmetic or funnel shifts of its own.
 //
 // Work per column and lane: NLW * (NP + 2) + NP VALU ops; for DNA and NLW = 3 that is 14 ops for what
 // the full-matrix kernel spends 4 * ceil(m / 32) + 2 on (130 for 1 kb).
@@ -38,8 +41,6 @@ namespace {
 using namespace malcs_dev;
 
 constexpr int META_ROWS = 4;          // pid, m, n, kmax | retry class << 16
-
-__host__ __device__ inline int diag_first_limb(int kmax) { return -((kmax + 31) >> 5); }
 
 // ---- plan-time layout --------------------------------------------------------------------------
 // grid (rows of the longest tile, tiles), block 64: thread = (tile, row r, lane)
@@ -64,32 +65,33 @@ k_diag_layout(const uint32_t *__restrict__ planes,
     uint32_t *out = rows + (size_t)tile_off[tile] * 64u + lane;
     if (r == 0) { out[0] = pid; out[64] = m; out[128] = n; out[192] = kc; }
     const int kmax = (int)(kc & 0xffffu);
-    const int R0 = diag_first_limb(kmax);
-    const int pblk = (int)((m + 31u) >> 5), tblk = (int)((n + q + 31u) >> 5);
+    const int pwords = (int)((m + q + 31u) >> 5), twords = (int)((n + q + 31u) >> 5);
     out += META_ROWS * 64;
-    // 32 rows from row 32 g of the pattern as cut; the word after a sequence's last one is its neighbour's or the
-    // arena's padding (rows beyond m never matter)
-    auto limb = [&](int g, int p) -> uint32_t {
-        if (g < 0 || g >= pblk) return 0u;
-        const uint32_t lo = planes[po + (uint32_t)g * NP + p];
-        return q ? ((lo >> q) | (planes[po + (uint32_t)(g + 1) * NP + p] << (32u - q))) : lo;
+    // 32 rows of the pattern from row rs (negative: above the matrix, those bits never matter) / 32 columns of the
+    // text from column 32 blk; both as cut, i.e. q symbols into the stored sequence
+    auto limb = [&](int rs, int p) -> uint32_t {
+        const int at = rs + (int)q, wd = at >> 5;                        // arithmetic shift = floor
+        const uint32_t sh = (uint32_t)at & 31u;
+        const uint32_t lo = (wd >= 0 && wd < pwords) ? planes[po + (uint32_t)wd * NP + p] : 0u;
+        const uint32_t hi = (wd + 1 >= 0 && wd + 1 < pwords) ? planes[po + (uint32_t)(wd + 1) * NP + p] : 0u;
+        return sh ? ((lo >> sh) | (hi << (32u - sh))) : lo;
     };
-    auto text = [&](int blk, int p) -> uint32_t { return (blk >= 0 && blk < tblk) ? planes[to + (uint32_t)blk * NP + p] : 0u; };
+    auto text = [&](int blk, int p) -> uint32_t {
+        const uint32_t lo = blk < twords ? planes[to + (uint32_t)blk * NP + p] : 0u;
+        const uint32_t hi = blk + 1 < twords ? planes[to + (uint32_t)(blk + 1) * NP + p] : 0u;
+        return q ? ((lo >> q) | (hi << (32u - q))) : lo;
+    };
     if (r < (uint32_t)(nlw - 1)) {
 #pragma unroll
-        for (int p = 0; p < NP; p++) out[(r * NP + p) * 64u] = limb(R0 + (int)r, p);
+        for (int p = 0; p < NP; p++) out[(r * NP + p) * 64u] = limb(32 * (int)r - kmax, p);
         return;
     }
     const int it = (int)r - (nlw - 1);
     out += (size_t)(nlw - 1) * NP * 64u + (size_t)it * 2u * NP * 64u;
-    const int c = 32 * (R0 + it) + kmax + (int)q;  // first column of this block in the stored text, may be negative in block 0
-    const int blk = c >> 5;                        // arithmetic shift = floor
-    const uint32_t sh = (uint32_t)c & 31u;
 #pragma unroll
     for (int p = 0; p < NP; p++) {
-        out[p * 64u] = limb(R0 + it + nlw - 1, p);
-        const uint32_t lo = text(blk, p), hi = text(blk + 1, p);
-        out[(NP + p) * 64u] = sh ? ((lo >> sh) | (hi << (32u - sh))) : lo;
+        out[p * 64u] = limb(32 * (it + nlw - 1) - kmax, p);
+        out[(NP + p) * 64u] = text(it, p);
     }
 }
 
@@ -401,35 +403,36 @@ k_llcs_diag(const uint32_t *__restrict__ rows, const uint32_t *__restrict__ tile
     const uint32_t *p = rows + (size_t)__builtin_amdgcn_readfirstlane(tile_off[tile]) * 64u + lane;
     const int iters = (int)__builtin_amdgcn_readfirstlane(tile_iters[tile]);
     const uint32_t pid = p[0], m = p[64], n = p[128], kc = p[192];
-    const int kmax = (int)(kc & 0xffffu);
-    const int R0 = diag_first_limb(kmax);
-    const int c0 = 32 * R0 + kmax;                 // column of step 0 of block 0, in (-32, 0]
+    const int kmax = (int)(kc & 0xffffu);          // block `it` = columns [32 it, 32 it + 32), its limb k = rows from 32 (it + k) - kmax
     p += META_ROWS * 64;
+
+    auto rowmask = [&](int rs) -> uint32_t {       // of the 32 rows from rs, those inside the matrix
+        const int vb = (int)m - rs;
+        const uint32_t below = vb >= 32 ? ~0u : (vb <= 0 ? 0u : ((1u << vb) - 1u));
+        const uint32_t above = rs >= 0 ? ~0u : (rs <= -32 ? 0u : (~0u << -rs));
+        return below & above;
+    };
 
     uint32_t P[NLW][NP], V[NLW];
 #pragma unroll
     for (int k = 0; k < NLW - 1; k++) {
 #pragma unroll
         for (int q = 0; q < NP; q++) P[k][q] = p[(k * NP + q) * 64];
-        V[k] = (R0 + k >= 0) ? ~0u : 0u;           // rows above the matrix: V = 0 neither matches nor carries
+        const int rs = 32 * k - kmax;              // rows above the matrix: V = 0 neither matches nor carries
+        V[k] = rs >= 0 ? ~0u : (rs <= -32 ? 0u : (~0u << -rs));
     }
     p += (NLW - 1) * NP * 64;
     uint32_t nxt[2 * NP];
     rows_load_async(p, nxt, std::make_integer_sequence<int, 2 * NP>());
     rows_wait(nxt);
 
-    auto rowmask = [&](int g) -> uint32_t {        // rows of limb g that exist
-        const int vb = (int)m - 32 * g;
-        return (g < 0 || vb <= 0) ? 0u : (vb >= 32 ? ~0u : ((1u << vb) - 1u));
-    };
     uint32_t banked = 0;
 
     // blocks [plain_lo, plain_hi) of a lane need no masks: all 32 columns exist and so do all rows of the leaving limb
     int plain_lo = 0, plain_hi = 0x7fffffff;
     if (pid != 0xffffffffu) {
-        plain_lo = max(c0 < 0 ? 1 : 0, -R0);
-        const int cols = (int)n - c0 - 32;
-        plain_hi = min(cols >= 0 ? cols / 32 + 1 : 0, (int)(m >> 5) - R0);
+        plain_lo = (kmax + 31) >> 5;
+        plain_hi = (int)min(n >> 5, (m + (uint32_t)kmax) >> 5);
     }
 
     for (int it = 0; it < iters;) {
@@ -445,16 +448,13 @@ k_llcs_diag(const uint32_t *__restrict__ rows, const uint32_t *__restrict__ tile
         for (int q = 0; q < NP; q++) { P[NLW - 1][q] = nxt[q]; w[q] = nxt[NP + q]; }
         V[NLW - 1] = ~0u;
         p += 2 * NP * 64;                          // rows of the next block (the buffer ends with one block of padding)
-        const int lo = -(c0 + 32 * it);            // first and one-past-last valid step of the block
-        const int hi = (int)n - (c0 + 32 * it);
-        const uint32_t mlo = lo <= 0 ? ~0u : (lo >= 32 ? 0u : (~0u << lo));
-        const uint32_t mhi = hi >= 32 ? ~0u : (hi <= 0 ? 0u : ((1u << hi) - 1u));
-        const uint32_t vm = mlo & mhi;
+        const int hi = (int)n - 32 * it;           // one past the last valid step of the block: steps beyond must not change V
+        const uint32_t vm = hi >= 32 ? ~0u : (hi <= 0 ? 0u : ((1u << hi) - 1u));
         const bool fast = __builtin_amdgcn_ballot_w64(vm != ~0u) == 0;
         if constexpr (NLW == 3 && NP == 2 && FUSED) {
             if (fast) {
                 diag_block_dna3(V, P, w, p, nxt);
-            } else {                               // first / last blocks: steps outside [0, n) must not change V
+            } else {                               // last blocks of a pair
                 rows_load_async(p, nxt, std::make_integer_sequence<int, 2 * NP>());
                 diag_block<NLW, NP, true>(V, P, w, vm, std::make_integer_sequence<int, 32 + NLW - 1>());
                 rows_wait(nxt);
@@ -466,7 +466,7 @@ k_llcs_diag(const uint32_t *__restrict__ rows, const uint32_t *__restrict__ tile
             rows_wait(nxt);
         }
         // the window moves down one limb
-        banked += __popc(~V[0] & rowmask(R0 + it));
+        banked += __popc(~V[0] & rowmask(32 * it - kmax));
 #pragma unroll
         for (int k = 0; k < NLW - 1; k++) {
             V[k] = V[k + 1];
@@ -477,7 +477,7 @@ k_llcs_diag(const uint32_t *__restrict__ rows, const uint32_t *__restrict__ tile
     }
     uint32_t zeros = banked;
 #pragma unroll
-    for (int k = 0; k < NLW - 1; k++) zeros += __popc(~V[k] & rowmask(R0 + iters + k));
+    for (int k = 0; k < NLW - 1; k++) zeros += __popc(~V[k] & rowmask(32 * (iters + k) - kmax));
 
     if (pid != 0xffffffffu) {
         const int32_t d = (int32_t)(m + n - 2u * zeros);
@@ -559,8 +559,7 @@ int malcs_diag_plan(malcs_batch *b, int nlw, const std::vector<uint32_t> &pairs,
             m -= pre + suf; n -= pre + suf;
         }
         const int kmax = delta + (T - delta) / 2;
-        const int c0 = 32 * diag_first_limb(kmax) + kmax;
-        items[i] = {pid, (uint32_t)kmax | ((uint32_t)retry_class[i] << 16), (uint32_t)(((int)n - 1 - c0) / 32 + 1), po, to, m, n, q};
+        items[i] = {pid, (uint32_t)kmax | ((uint32_t)retry_class[i] << 16), (n + 31u) / 32u, po, to, m, n, q};
         cells += (uint64_t)(32 * nlw) * n;
     }
     std::stable_sort(items.begin(), items.end(), [](const item &x, const item &y) { return x.iters < y.iters; });
