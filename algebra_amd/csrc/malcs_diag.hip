@@ -428,17 +428,19 @@ k_llcs_diag(const uint32_t *__restrict__ rows, const uint32_t *__restrict__ tile
 
     uint32_t banked = 0;
 
-    // blocks [plain_lo, plain_hi) of a lane need no masks: all 32 columns exist and so do all rows of the leaving limb
-    int plain_lo = 0, plain_hi = 0x7fffffff;
+    // blocks [0, plain_hi) of a lane need no masks: all 32 columns exist and the leaving limb has no rows beyond the
+    // matrix.  Rows above the matrix (V = 0 from the start, so they read as zero bits) all leave with the first three
+    // limbs: when those are banked without a mask, `above` takes them out again.
+    int plain_hi = 0x7fffffff, above = 0;
     if (pid != 0xffffffffu) {
-        plain_lo = (kmax + 31) >> 5;
         plain_hi = (int)min(n >> 5, (m + (uint32_t)kmax) >> 5);
     }
 
     for (int it = 0; it < iters;) {
         if constexpr (NLW == 3 && NP == 2 && FUSED) {
-            auto plain3 = [&](int i) { return i + 3 <= iters && __builtin_amdgcn_ballot_w64(i < plain_lo || i + 3 > plain_hi) == 0; };
+            auto plain3 = [&](int i) { return i + 3 <= iters && __builtin_amdgcn_ballot_w64(i + 3 > plain_hi) == 0; };
             if (plain3(it)) {
+                if (it == 0) above = kmax;                 // kmax <= 64: rows [-kmax, 0) lie in the first three leaving limbs
                 diag_triples_dna3(V, P, banked, p, nxt, it, plain3);
                 continue;
             }
@@ -475,7 +477,7 @@ k_llcs_diag(const uint32_t *__restrict__ rows, const uint32_t *__restrict__ tile
         }
         it++;
     }
-    uint32_t zeros = banked;
+    uint32_t zeros = banked - (uint32_t)above;
 #pragma unroll
     for (int k = 0; k < NLW - 1; k++) zeros += __popc(~V[k] & rowmask(32 * (iters + k) - kmax));
 
