@@ -557,6 +557,9 @@ int malcs_diag_plan(malcs_batch *b, int nlw, const std::vector<uint32_t> &pairs,
             while (pre < room && x[pre] == y[pre]) pre++;
             uint32_t suf = 0;
             while (suf < room - pre && x[m - 1 - suf] == y[n - 1 - suf]) suf++;
+            // a text of whole blocks has no masked last block: give back up to 31 of the cut symbols for that
+            const uint32_t ragged = (32u - ((n - pre - suf) & 31u)) & 31u;
+            if (ragged && ragged <= pre + suf) { const uint32_t back = std::min(ragged, suf); suf -= back; pre -= ragged - back; }
             po += (pre >> 5) * NP; to += (pre >> 5) * NP; q = pre & 31u;
             m -= pre + suf; n -= pre + suf;
         }
@@ -564,7 +567,11 @@ int malcs_diag_plan(malcs_batch *b, int nlw, const std::vector<uint32_t> &pairs,
         items[i] = {pid, (uint32_t)kmax | ((uint32_t)retry_class[i] << 16), (n + 31u) / 32u, po, to, m, n, q};
         cells += (uint64_t)(32 * nlw) * n;
     }
-    std::stable_sort(items.begin(), items.end(), [](const item &x, const item &y) { return x.iters < y.iters; });
+    // tiles of equal length, and the pairs whose text is whole blocks together (their tiles never leave the plain path)
+    std::stable_sort(items.begin(), items.end(), [](const item &x, const item &y) {
+        const bool rx = (x.n & 31u) != 0, ry = (y.n & 31u) != 0;
+        return rx != ry ? ry : x.iters < y.iters;
+    });
     const uint32_t n_tiles = (uint32_t)((items.size() + 63) / 64);
     std::vector<uint32_t> tile_pid((size_t)n_tiles * 64, 0xffffffffu), tile_kc((size_t)n_tiles * 64, 0u);
     std::vector<uint32_t> tile_seq((size_t)n_tiles * 64 * 5, 0u);          // po, to, m, n, q of every slot (five arrays back to back)
