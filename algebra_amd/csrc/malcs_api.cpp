@@ -192,6 +192,7 @@ static int batch_build(malcs_ctx *ctx, const uint8_t *syms, uint64_t n_syms,
                        const uint64_t *a_off, const uint32_t *a_len, const uint64_t *b_off, const uint32_t *b_len,
                        uint64_t n_pairs, int n_symbols, malcs_batch *b)
 {
+    malcs_stage_trace trace("batch_create");
     b->ctx = ctx;
     b->n_pairs = n_pairs;
     b->n_planes = planes_for(n_symbols);
@@ -234,6 +235,7 @@ static int batch_build(malcs_ctx *ctx, const uint8_t *syms, uint64_t n_syms,
     }
     const uint32_t n_seqs = (uint32_t)seq_len.size();
     b->arena_dwords = total_blocks * NP;
+    trace.lap("distinct sequences");
 
     MALCS_HIP(hipSetDevice(ctx->device));
     hipStream_t st = ctx->stream;
@@ -260,9 +262,11 @@ static int batch_build(malcs_ctx *ctx, const uint8_t *syms, uint64_t n_syms,
         }
         MALCS_HIP(malcs_sync(st));
     }
+    trace.lap("allocations, copies to the device, bit planes");
     b->raw_syms = syms; b->raw_a_off = a_off; b->raw_b_off = b_off;
     const int rc = malcs_dist_plan(b);
     b->raw_syms = nullptr; b->raw_a_off = b->raw_b_off = nullptr;
+    trace.lap("distance plan");
     return rc;
 }
 

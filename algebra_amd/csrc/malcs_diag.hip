@@ -33,7 +33,10 @@
 #include "malcs_internal.hpp"
 #include "malcs_device.hpp"
 #include <algorithm>
+#include <atomic>
 #include <cstdlib>
+#include <cstring>
+#include <thread>
 #include <utility>
 
 namespace {
@@ -531,6 +534,7 @@ int malcs_diag_plan(malcs_batch *b, int nlw, const std::vector<uint32_t> &pairs,
         return MALCS_ERR_INTERNAL;
     }
     const int T = malcs_diag_threshold(nlw);
+    malcs_stage_trace trace("window plan");
     // Common ends do not change the distance (the reference's sweep slides through them in one snake, LCSgraph.from_sequence
     // cuts them off with trim(), lcs_graph.py:231-235): they are left out of the window (the layout kernel shifts pattern and
     // text by what is cut in front), as long as enough rows for the window class remain.  Needs the caller's symbols, so
@@ -540,33 +544,62 @@ int malcs_diag_plan(malcs_batch *b, int nlw, const std::vector<uint32_t> &pairs,
     const uint32_t NP = (uint32_t)b->n_planes;
     struct item { uint32_t pid, kc, iters, po, to, m, n, q; };
     std::vector<item> items(pairs.size());
-    uint64_t cells = 0;
-    for (size_t i = 0; i < pairs.size(); i++) {
-        const uint32_t pid = pairs[i];
-        const bool a_short = b->a_len[pid] <= b->b_len[pid];
-        uint32_t m = a_short ? b->a_len[pid] : b->b_len[pid], n = a_short ? b->b_len[pid] : b->a_len[pid];
-        uint32_t po = a_short ? b->a_off[pid] : b->b_off[pid], to = a_short ? b->b_off[pid] : b->a_off[pid];
-        uint32_t q = 0;
-        const int delta = (int)(n - m);
-        if (delta > T || n == 0) { malcs_set_error("pair %u does not fit the window class", pid); return MALCS_ERR_INTERNAL; }
-        if (trim && m > min_rows) {
-            const uint8_t *x = b->raw_syms + (a_short ? b->raw_a_off[pid] : b->raw_b_off[pid]);     // pattern, m symbols
-            const uint8_t *y = b->raw_syms + (a_short ? b->raw_b_off[pid] : b->raw_a_off[pid]);     // text, n symbols
-            const uint32_t room = m - min_rows;
-            uint32_t pre = 0;
-            while (pre < room && x[pre] == y[pre]) pre++;
-            uint32_t suf = 0;
-            while (suf < room - pre && x[m - 1 - suf] == y[n - 1 - suf]) suf++;
-            // a text of whole blocks has no masked last block: give back up to 31 of the cut symbols for that
-            const uint32_t ragged = (32u - ((n - pre - suf) & 31u)) & 31u;
-            if (ragged && ragged <= pre + suf) { const uint32_t back = std::min(ragged, suf); suf -= back; pre -= ragged - back; }
-            po += (pre >> 5) * NP; to += (pre >> 5) * NP; q = pre & 31u;
-            m -= pre + suf; n -= pre + suf;
+    std::atomic<uint64_t> cells_sum{0};
+    std::atomic<uint32_t> misfit{0xffffffffu};
+    auto plan_items = [&](size_t first, size_t last) {
+        uint64_t cells = 0;
+        for (size_t i = first; i < last; i++) {
+            const uint32_t pid = pairs[i];
+            const bool a_short = b->a_len[pid] <= b->b_len[pid];
+            uint32_t m = a_short ? b->a_len[pid] : b->b_len[pid], n = a_short ? b->b_len[pid] : b->a_len[pid];
+            uint32_t po = a_short ? b->a_off[pid] : b->b_off[pid], to = a_short ? b->b_off[pid] : b->a_off[pid];
+            uint32_t q = 0;
+            const int delta = (int)(n - m);
+            if (delta > T || n == 0) { misfit.store(pid); return; }
+            if (trim && m > min_rows) {
+                const uint8_t *x = b->raw_syms + (a_short ? b->raw_a_off[pid] : b->raw_b_off[pid]);     // pattern, m symbols
+                const uint8_t *y = b->raw_syms + (a_short ? b->raw_b_off[pid] : b->raw_a_off[pid]);     // text, n symbols
+                const uint32_t room = m - min_rows;
+                uint32_t pre = 0;
+                while (pre + 8 <= room) {                    // eight symbols at a time
+                    uint64_t wx, wy;
+                    memcpy(&wx, x + pre, 8); memcpy(&wy, y + pre, 8);
+                    if (wx != wy) break;
+                    pre += 8;
+                }
+                while (pre < room && x[pre] == y[pre]) pre++;
+                uint32_t suf = 0;
+                const uint8_t *xe = x + m, *ye = y + n;
+                while (suf + 8 <= room - pre) {
+                    uint64_t wx, wy;
+                    memcpy(&wx, xe - suf - 8, 8); memcpy(&wy, ye - suf - 8, 8);
+                    if (wx != wy) break;
+                    suf += 8;
+                }
+                while (suf < room - pre && xe[-1 - (ptrdiff_t)suf] == ye[-1 - (ptrdiff_t)suf]) suf++;
+                // a text of whole blocks has no masked last block: give back up to 31 of the cut symbols for that
+                const uint32_t ragged = (32u - ((n - pre - suf) & 31u)) & 31u;
+                if (ragged && ragged <= pre + suf) { const uint32_t back = std::min(ragged, suf); suf -= back; pre -= ragged - back; }
+                po += (pre >> 5) * NP; to += (pre >> 5) * NP; q = pre & 31u;
+                m -= pre + suf; n -= pre + suf;
+            }
+            const int kmax = delta + (T - delta) / 2;
+            items[i] = {pid, (uint32_t)kmax | ((uint32_t)retry_class[i] << 16), (n + 31u) / 32u, po, to, m, n, q};
+            cells += (uint64_t)(32 * nlw) * n;
         }
-        const int kmax = delta + (T - delta) / 2;
-        items[i] = {pid, (uint32_t)kmax | ((uint32_t)retry_class[i] << 16), (n + 31u) / 32u, po, to, m, n, q};
-        cells += (uint64_t)(32 * nlw) * n;
+        cells_sum += cells;
+    };
+    {
+        // the scan of the ends is a cache miss or two per sequence: threads from a few thousand pairs on
+        const size_t nt = pairs.size() < 4096 ? 1 : std::min<size_t>(16, std::max(1u, std::thread::hardware_concurrency()));
+        std::vector<std::thread> pool;
+        for (size_t t = 1; t < nt; t++) pool.emplace_back(plan_items, pairs.size() * t / nt, pairs.size() * (t + 1) / nt);
+        plan_items(0, pairs.size() / nt);
+        for (std::thread &t : pool) t.join();
     }
+    if (misfit.load() != 0xffffffffu) { malcs_set_error("pair %u does not fit the window class", misfit.load()); return MALCS_ERR_INTERNAL; }
+    const uint64_t cells = cells_sum.load();
+    trace.lap("common ends");
     // tiles of equal length, and the pairs whose text is whole blocks together (their tiles never leave the plain path)
     std::stable_sort(items.begin(), items.end(), [](const item &x, const item &y) {
         const bool rx = (x.n & 31u) != 0, ry = (y.n & 31u) != 0;
@@ -624,6 +657,7 @@ int malcs_diag_plan(malcs_batch *b, int nlw, const std::vector<uint32_t> &pairs,
     }
     tile_off[n_tiles] = (uint32_t)row;
 
+    trace.lap("sort, deal, tile arrays");
     // retry bookkeeping: one list segment per full-matrix class, sized for the worst case
     d.retry = classes;
     std::vector<uint32_t> cap(classes.size(), 0), first(classes.size(), 0);
@@ -663,6 +697,7 @@ int malcs_diag_plan(malcs_batch *b, int nlw, const std::vector<uint32_t> &pairs,
     }
     MALCS_HIP(hipGetLastError());
     MALCS_HIP(malcs_sync(st));           // the host vectors above are locals
+    trace.lap("allocations, copies, layout kernel");
     d.nlw = nlw; d.T = T; d.n_tiles = n_tiles; d.n_pairs = (uint32_t)pairs.size(); d.window_cells = cells;
     return MALCS_OK;
 }

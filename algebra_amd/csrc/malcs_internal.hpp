@@ -4,6 +4,9 @@
 #include <cstdint>
 #include <cstdio>
 #include <string>
+#include <chrono>
+#include <cstdio>
+#include <cstdlib>
 #include <vector>
 #include "../../include/malcs.h"
 
@@ -17,6 +20,21 @@ void malcs_set_error(const char *fmt, ...);
             return MALCS_ERR_HIP;                                                             \
         }                                                                                     \
     } while (0)
+
+// MALCS_TRACE=1: wall time of the stages of a host-side call, to stderr (dev aid; costs one getenv per call when off)
+struct malcs_stage_trace {
+    bool on;
+    const char *what;
+    std::chrono::steady_clock::time_point t0;
+    explicit malcs_stage_trace(const char *w) : on(getenv("MALCS_TRACE") != nullptr), what(w), t0(std::chrono::steady_clock::now()) {}
+    void lap(const char *stage)
+    {
+        if (!on) return;
+        const auto t1 = std::chrono::steady_clock::now();
+        fprintf(stderr, "[malcs] %s: %s %.2f ms\n", what, stage, std::chrono::duration<double, std::milli>(t1 - t0).count());
+        t0 = t1;
+    }
+};
 
 // device memory that is released on every return path of the function that holds it
 template <typename T> struct dev_scoped {
