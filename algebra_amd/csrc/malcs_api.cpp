@@ -199,20 +199,23 @@ static int batch_build(malcs_ctx *ctx, const uint8_t *syms, uint64_t n_syms,
     const uint32_t NP = (uint32_t)b->n_planes;
 
     // distinct sequences (pairs may share them: a relation-matrix tile re-uses every window many times)
-    struct key { uint64_t off; uint32_t len; bool operator==(const key &o) const { return off == o.off && len == o.len; } };
-    struct key_hash { size_t operator()(const key &k) const { return (size_t)(k.off * 0x9e3779b97f4a7c15ull) ^ ((size_t)k.len * 0xc2b2ae3d27d4eb4full); } };
-    std::unordered_map<key, uint32_t, key_hash> index;
-    index.reserve((size_t)n_pairs * 2 + 1);
+    // open addressing over (offset, length); the table holds sequence ids, empty slots are ~0
+    size_t table_size = 16;
+    while (table_size < (size_t)n_pairs * 4 + 4) table_size <<= 1;
+    std::vector<uint32_t> table(table_size, 0xffffffffu);
     std::vector<uint64_t> seq_byte_off;
     std::vector<uint32_t> seq_len, seq_blk_off;
+    seq_byte_off.reserve((size_t)n_pairs * 2); seq_len.reserve((size_t)n_pairs * 2); seq_blk_off.reserve((size_t)n_pairs * 2);
     uint64_t total_blocks = 0;
     auto intern = [&](uint64_t off, uint32_t len, uint32_t *id) -> int {
         if (off > n_syms || (uint64_t)len > n_syms - off) { malcs_set_error("sequence [%llu,+%u) outside the symbol buffer of %llu bytes", (unsigned long long)off, len, (unsigned long long)n_syms); return MALCS_ERR_ARG; }
-        key k{off, len};
-        auto it = index.find(k);
-        if (it != index.end()) { *id = it->second; return MALCS_OK; }
+        size_t slot = (size_t)((off * 0x9e3779b97f4a7c15ull) ^ ((uint64_t)len * 0xc2b2ae3d27d4eb4full)) >> 20 & (table_size - 1);
+        for (; table[slot] != 0xffffffffu; slot = (slot + 1) & (table_size - 1)) {
+            const uint32_t have = table[slot];
+            if (seq_byte_off[have] == off && seq_len[have] == len) { *id = have; return MALCS_OK; }
+        }
+        table[slot] = (uint32_t)seq_len.size();
         *id = (uint32_t)seq_len.size();
-        index.emplace(k, *id);
         seq_byte_off.push_back(off);
         seq_len.push_back(len);
         seq_blk_off.push_back((uint32_t)total_blocks);

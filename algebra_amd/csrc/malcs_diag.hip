@@ -601,10 +601,18 @@ int malcs_diag_plan(malcs_batch *b, int nlw, const std::vector<uint32_t> &pairs,
     const uint64_t cells = cells_sum.load();
     trace.lap("common ends");
     // tiles of equal length, and the pairs whose text is whole blocks together (their tiles never leave the plain path)
-    std::stable_sort(items.begin(), items.end(), [](const item &x, const item &y) {
-        const bool rx = (x.n & 31u) != 0, ry = (y.n & 31u) != 0;
-        return rx != ry ? ry : x.iters < y.iters;
-    });
+    // (a stable counting sort: key = whole blocks first, then the number of blocks)
+    {
+        uint32_t max_it = 0;
+        for (const item &x : items) max_it = std::max(max_it, x.iters);
+        auto key_of = [&](const item &x) -> size_t { return ((x.n & 31u) ? (size_t)max_it + 1 : 0) + x.iters; };
+        std::vector<size_t> start(2 * ((size_t)max_it + 1) + 1, 0);
+        for (const item &x : items) start[key_of(x) + 1]++;
+        for (size_t k = 1; k < start.size(); k++) start[k] += start[k - 1];
+        std::vector<item> sorted(items.size());
+        for (const item &x : items) sorted[start[key_of(x)]++] = x;
+        items.swap(sorted);
+    }
     const uint32_t n_tiles = (uint32_t)((items.size() + 63) / 64);
     std::vector<uint32_t> tile_pid((size_t)n_tiles * 64, 0xffffffffu), tile_kc((size_t)n_tiles * 64, 0u);
     std::vector<uint32_t> tile_seq((size_t)n_tiles * 64 * 5, 0u);          // po, to, m, n, q of every slot (five arrays back to back)
