@@ -4,7 +4,6 @@
 #include <cstdarg>
 #include <cstring>
 #include <new>
-#include <unordered_map>
 
 static thread_local char g_last_error[512] = "";
 

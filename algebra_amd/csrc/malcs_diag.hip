@@ -36,6 +36,7 @@
 #include <atomic>
 #include <cstdlib>
 #include <cstring>
+#include <system_error>
 #include <thread>
 #include <utility>
 
@@ -593,8 +594,12 @@ int malcs_diag_plan(malcs_batch *b, int nlw, const std::vector<uint32_t> &pairs,
         // the scan of the ends is a cache miss or two per sequence: threads from a few thousand pairs on
         const size_t nt = pairs.size() < 4096 ? 1 : std::min<size_t>(16, std::max(1u, std::thread::hardware_concurrency()));
         std::vector<std::thread> pool;
-        for (size_t t = 1; t < nt; t++) pool.emplace_back(plan_items, pairs.size() * t / nt, pairs.size() * (t + 1) / nt);
+        size_t started = 1;                                 // shares [0, started) of nt are taken
+        try {
+            for (; started < nt; started++) pool.emplace_back(plan_items, pairs.size() * started / nt, pairs.size() * (started + 1) / nt);
+        } catch (const std::system_error &) {}              // no more threads to be had: this one does the rest
         plan_items(0, pairs.size() / nt);
+        if (started < nt) plan_items(pairs.size() * started / nt, pairs.size());
         for (std::thread &t : pool) t.join();
     }
     if (misfit.load() != 0xffffffffu) { malcs_set_error("pair %u does not fit the window class", misfit.load()); return MALCS_ERR_INTERNAL; }
