@@ -641,14 +641,24 @@ int malcs_diag_plan(malcs_batch *b, int nlw, const std::vector<uint32_t> &pairs,
         std::vector<simd_load> heap;
         for (uint32_t i = 0; i < std::min(S, n_tiles); i++) heap.push_back({0, (n_tiles - i + S - 1) / S, 0, i});
         std::make_heap(heap.begin(), heap.end(), worse);
-        for (uint32_t r = 0; r < n_tiles; r++) {
-            const uint32_t j = n_tiles - 1 - r;                // longest first
-            uint32_t it = 1;
-            for (size_t i = (size_t)j * 64; i < std::min(items.size(), (size_t)(j + 1) * 64); i++) it = std::max(it, items[i].iters);
+        // cost of a tile in sixteenths of a plain block: a last block with masked steps costs 1.6 plain ones
+        std::vector<std::pair<uint32_t, uint32_t>> by_cost(n_tiles);
+        for (uint32_t j = 0; j < n_tiles; j++) {
+            uint32_t it = 1, ragged = 0;
+            for (size_t i = (size_t)j * 64; i < std::min(items.size(), (size_t)(j + 1) * 64); i++) {
+                it = std::max(it, items[i].iters);
+                ragged |= items[i].n & 31u;
+            }
+            by_cost[j] = {16u * it + (ragged ? 10u : 0u), j};
+        }
+        std::sort(by_cost.begin(), by_cost.end(), [](const std::pair<uint32_t, uint32_t> &x, const std::pair<uint32_t, uint32_t> &y) {
+            return x.first != y.first ? x.first > y.first : x.second < y.second;
+        });
+        for (uint32_t r = 0; r < n_tiles; r++) {               // most expensive first
             std::pop_heap(heap.begin(), heap.end(), worse);
             simd_load &top = heap.back();
-            tile_at[top.idx + top.used * S] = j;
-            top.used++; top.load += it;
+            tile_at[top.idx + top.used * S] = by_cost[r].second;
+            top.used++; top.load += by_cost[r].first;
             if (top.used == top.slots) heap.pop_back(); else std::push_heap(heap.begin(), heap.end(), worse);
         }
     }
