@@ -45,6 +45,7 @@ namespace {
 using namespace malcs_dev;
 
 constexpr int META_ROWS = 4;          // pid, m, n, kmax | retry class << 16
+constexpr int MALCS_DIAG_HALF_T = 48; // two limbs moving 16 rows per 16 columns: 64 - 16 diagonals
 
 // ---- plan-time layout --------------------------------------------------------------------------
 // grid (rows of the longest tile, tiles), block 64: thread = (tile, row r, lane)
@@ -53,12 +54,13 @@ __global__ void __launch_bounds__(64)
 k_diag_layout(const uint32_t *__restrict__ planes,
               const uint32_t *__restrict__ tile_po, const uint32_t *__restrict__ tile_to,
               const uint32_t *__restrict__ tile_m, const uint32_t *__restrict__ tile_n, const uint32_t *__restrict__ tile_q,
+              const uint32_t *__restrict__ tile_mt, const uint32_t *__restrict__ tile_nt,
               const uint32_t *__restrict__ tile_pid, const uint32_t *__restrict__ tile_kc,
               const uint32_t *__restrict__ tile_off, const uint32_t *__restrict__ tile_iters,
               int nlw, uint32_t *__restrict__ rows)
 {
     const uint32_t tile = blockIdx.y, r = blockIdx.x, lane = threadIdx.x;
-    const uint32_t iters = tile_iters[tile];
+    const uint32_t iters = tile_iters[tile] & 0x7fffffffu;         // bit 31: the tile runs in two-limb mode (same rows)
     if (r >= (uint32_t)(nlw - 1) + iters) return;
     const uint32_t slot = tile * 64u + lane;
     const uint32_t pid = tile_pid[slot];
@@ -66,24 +68,31 @@ k_diag_layout(const uint32_t *__restrict__ planes,
     // pattern (the shorter sequence) and text of the slot, common ends already cut off by the plan: both start q symbols
     // (0 ... 31) into the block at po / to and have m / n symbols from there
     const uint32_t m = tile_m[slot], n = tile_n[slot], po = tile_po[slot], to = tile_to[slot], q = tile_q[slot];
+    // symbols really stored from po / to on; m and n may reach beyond them: the plan lengthens both sequences by the same
+    // number of symbols to make the text whole blocks, and what lies beyond the end reads as symbol 0 on both sides --
+    // a common suffix, which does not change the distance
+    const int mt = (int)tile_mt[slot], nt = (int)tile_nt[slot];
     uint32_t *out = rows + (size_t)tile_off[tile] * 64u + lane;
     if (r == 0) { out[0] = pid; out[64] = m; out[128] = n; out[192] = kc; }
     const int kmax = (int)(kc & 0xffffu);
-    const int pwords = (int)((m + q + 31u) >> 5), twords = (int)((n + q + 31u) >> 5);
     out += META_ROWS * 64;
+    auto stored = [&](uint32_t base, int have, int wd, int p) -> uint32_t {    // word wd of a stored sequence, zero beyond its end
+        const int valid = have - 32 * wd;
+        if (wd < 0 || valid <= 0) return 0u;
+        const uint32_t w = planes[base + (uint32_t)wd * NP + p];
+        return valid >= 32 ? w : (w & ((1u << valid) - 1u));
+    };
     // 32 rows of the pattern from row rs (negative: above the matrix, those bits never matter) / 32 columns of the
     // text from column 32 blk; both as cut, i.e. q symbols into the stored sequence
     auto limb = [&](int rs, int p) -> uint32_t {
         const int at = rs + (int)q, wd = at >> 5;                        // arithmetic shift = floor
         const uint32_t sh = (uint32_t)at & 31u;
-        const uint32_t lo = (wd >= 0 && wd < pwords) ? planes[po + (uint32_t)wd * NP + p] : 0u;
-        const uint32_t hi = (wd + 1 >= 0 && wd + 1 < pwords) ? planes[po + (uint32_t)(wd + 1) * NP + p] : 0u;
-        return sh ? ((lo >> sh) | (hi << (32u - sh))) : lo;
+        const uint32_t lo = stored(po, mt, wd, p);
+        return sh ? ((lo >> sh) | (stored(po, mt, wd + 1, p) << (32u - sh))) : lo;
     };
     auto text = [&](int blk, int p) -> uint32_t {
-        const uint32_t lo = blk < twords ? planes[to + (uint32_t)blk * NP + p] : 0u;
-        const uint32_t hi = blk + 1 < twords ? planes[to + (uint32_t)(blk + 1) * NP + p] : 0u;
-        return q ? ((lo >> q) | (hi << (32u - q))) : lo;
+        const uint32_t lo = stored(to, nt, blk, p);
+        return q ? ((lo >> q) | (stored(to, nt, blk + 1, p) << (32u - q))) : lo;
     };
     if (r < (uint32_t)(nlw - 1)) {
 #pragma unroll
@@ -362,6 +371,72 @@ __device__ __forceinline__ void diag_triples_dna3(uint32_t (&V)[3], uint32_t (&P
     banked = bank;
 }
 
+// ---- two limbs, half-limb steps --------------------------------------------------------------------
+// The distances of a similar batch need fewer diagonals than three limbs cover.  Two limbs that move down 16 rows per
+// 16 columns cover T = 48 (64 rows - 16) for 10.75 instead of 14.5 instructions per column (tools/two_limb_rate.hip:
+// 16.5 against 21.7 ns per column and wave at two waves per SIMD).  The rows are the ones the three-limb class reads
+// (two limbs to start with, per block the limb that enters and the text word): the window of 64 rows lies in the
+// pattern limbs a, b (first 16 columns of a block) and in a, b, c shifted by 16 (last 16; four v_alignbit into
+// v45 / v49 / v53 / v57).  After 16 columns the low half of V0 leaves: its ONE bits are banked (the zeros follow from
+// the number of half steps), V moves down by v_alignbit and all ones enter on top.  Only for tiles whose lanes all
+// have the same whole number of blocks: there is no masked path here.
+#define HG_REGS0 "v20", "v21", "v33", "v24", "v25", "v37"
+#define HG_REGS1 "v20", "v45", "v49", "v24", "v53", "v57"
+#define HG_DRAIN_(B0, B1, I1, I2, V0, P00, P01, V1, P10, P11) \
+    TG_Ua("v26", V1, P10, B0) TG_Ub("v26", P11, B1) TG_ADC("v27", "s[48:49]", V1, "v26", I1) TG_N(V1, "v26", "v27")
+#define HG_DRAIN(B, I, V0, P00, P01, V1, P10, P11) HG_DRAIN_(B, I, V0, P00, P01, V1, P10, P11)
+#define HG_FILL0(s, V0, P00, P01, V1, P10, P11) TG_FILL0(s, DG_X0, DG_CE, V0, P00, P01)
+#define HG_ODD(s, V0, P00, P01, V1, P10, P11) TG_FILL1(s, DG_X1, DG_X0, DG_CE, DG_CO, V0, P00, P01, V1, P10, P11)
+#define HG_EVEN(s, V0, P00, P01, V1, P10, P11) TG_FILL1(s, DG_X0, DG_X1, DG_CO, DG_CE, V0, P00, P01, V1, P10, P11)
+#define HG_HALF_(s0, s1, s2, s3, s4, s5, s6, s7, s8, s9, s10, s11, s12, s13, s14, s15, V0, P00, P01, V1, P10, P11)    \
+    ".p2align 3\n\ts_nop 0\n\t"                                                                                         \
+    HG_FILL0(s0, V0, P00, P01, V1, P10, P11) HG_ODD(s1, V0, P00, P01, V1, P10, P11) HG_EVEN(s2, V0, P00, P01, V1, P10, P11) \
+    HG_ODD(s3, V0, P00, P01, V1, P10, P11) HG_EVEN(s4, V0, P00, P01, V1, P10, P11) HG_ODD(s5, V0, P00, P01, V1, P10, P11)  \
+    HG_EVEN(s6, V0, P00, P01, V1, P10, P11) HG_ODD(s7, V0, P00, P01, V1, P10, P11) HG_EVEN(s8, V0, P00, P01, V1, P10, P11) \
+    HG_ODD(s9, V0, P00, P01, V1, P10, P11) HG_EVEN(s10, V0, P00, P01, V1, P10, P11) HG_ODD(s11, V0, P00, P01, V1, P10, P11) \
+    HG_EVEN(s12, V0, P00, P01, V1, P10, P11) HG_ODD(s13, V0, P00, P01, V1, P10, P11) HG_EVEN(s14, V0, P00, P01, V1, P10, P11) \
+    HG_ODD(s15, V0, P00, P01, V1, P10, P11) HG_DRAIN(DG_X1, DG_CO, V0, P00, P01, V1, P10, P11)
+#define HG_HALF(s0, s1, s2, s3, s4, s5, s6, s7, s8, s9, s10, s11, s12, s13, s14, s15, R) \
+    HG_HALF_(s0, s1, s2, s3, s4, s5, s6, s7, s8, s9, s10, s11, s12, s13, s14, s15, R)
+// the low 16 rows leave (ones counted), 16 fresh rows enter
+#define HG_DOWN "v_and_b32 v22, 0xffff, v20\n\tv_bcnt_u32_b32 %[bank], v22, %[bank]\n\t" \
+                "v_alignbit_b32 v20, v24, v20, 16\n\tv_alignbit_b32 v24, -1, v24, 16\n\t"
+
+// All blocks of a tile.  On entry nxt holds the rows of block 0 and p points at them, V[0], V[1] / P[0], P[1] are the
+// limbs the window starts with; `ones` collects the one bits of the rows that leave (32 per block).
+__device__ __forceinline__ void diag_halves_dna(uint32_t (&V)[3], uint32_t (&P)[3][2], uint32_t &ones,
+                                                const uint32_t *&p, uint32_t (&nxt)[4], int iters)
+{
+    register uint32_t V0 asm("v20") = V[0], V1 asm("v24") = V[1];
+    register uint32_t P00 asm("v21") = P[0][0], P10 asm("v25") = P[1][0], P20 asm("v29");
+    register uint32_t P01 asm("v33") = P[0][1], P11 asm("v37") = P[1][1], P21 asm("v41");
+    register uint32_t w0 asm("v32"), w1 asm("v36");
+    uint32_t n0 = nxt[0], n1 = nxt[1], n2 = nxt[2], n3 = nxt[3], bank = ones;
+    int it = 0;
+    do {
+        asm volatile(
+            "v_mov_b32 v29, %[n0]\n\tv_mov_b32 v41, %[n1]\n\tv_mov_b32 v32, %[n2]\n\tv_mov_b32 v36, %[n3]\n\t"
+            TG_LOADS(1024, 1280, 1536, 1792)
+            HG_HALF(0, 1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11, 12, 13, 14, 15, HG_REGS0)
+            HG_DOWN
+            "v_alignbit_b32 v45, v25, v21, 16\n\tv_alignbit_b32 v49, v37, v33, 16\n\t"
+            "v_alignbit_b32 v53, v29, v25, 16\n\tv_alignbit_b32 v57, v41, v37, 16\n\t"
+            HG_HALF(16, 17, 18, 19, 20, 21, 22, 23, 24, 25, 26, 27, 28, 29, 30, 31, HG_REGS1)
+            HG_DOWN
+            "v_mov_b32 v21, v25\n\tv_mov_b32 v33, v37\n\tv_mov_b32 v25, v29\n\tv_mov_b32 v37, v41\n\t"
+            "s_waitcnt vmcnt(0)"
+            : "+v"(V0), "+v"(V1), "+v"(P00), "+v"(P01), "+v"(P10), "+v"(P11), "=v"(P20), "=v"(P21),
+              [w0] "=v"(w0), [w1] "=v"(w1), [bank] "+v"(bank), [n0] "+v"(n0), [n1] "+v"(n1), [n2] "+v"(n2), [n3] "+v"(n3)
+            : [np] "v"(p)
+            : "v22", "v26", "v23", "v27", "v35", "v47", "v39", "v51", "v45", "v49", "v53", "v57",
+              "s40", "s41", "s42", "s43", "s44", "s45", "s46", "s47", "s48", "s49");
+        p += 4 * 64;
+    } while (++it < iters);
+    V[0] = V0; V[1] = V1;
+    nxt[0] = n0; nxt[1] = n1; nxt[2] = n2; nxt[3] = n3;
+    ones = bank;
+}
+
 // The same for the other classes: loads the compiler does not see, and a wait statement that every
 // destination passes through before its first use (the loads are unconditional: the buffer is padded).
 template <int J>
@@ -405,7 +480,9 @@ k_llcs_diag(const uint32_t *__restrict__ rows, const uint32_t *__restrict__ tile
     const unsigned lane = threadIdx.x;
     const uint32_t tile = blockIdx.x;
     const uint32_t *p = rows + (size_t)__builtin_amdgcn_readfirstlane(tile_off[tile]) * 64u + lane;
-    const int iters = (int)__builtin_amdgcn_readfirstlane(tile_iters[tile]);
+    const uint32_t mode_iters = __builtin_amdgcn_readfirstlane(tile_iters[tile]);
+    const int iters = (int)(mode_iters & 0x7fffffffu);
+    const bool halves = NLW == 3 && NP == 2 && FUSED && (mode_iters >> 31);     // two limbs, half-limb steps (T = 48)
     const uint32_t pid = p[0], m = p[64], n = p[128], kc = p[192];
     const int kmax = (int)(kc & 0xffffu);          // block `it` = columns [32 it, 32 it + 32), its limb k = rows from 32 (it + k) - kmax
     p += META_ROWS * 64;
@@ -440,7 +517,15 @@ k_llcs_diag(const uint32_t *__restrict__ rows, const uint32_t *__restrict__ tile
         plain_hi = (int)min(n >> 5, (m + (uint32_t)kmax) >> 5);
     }
 
-    for (int it = 0; it < iters;) {
+    if constexpr (NLW == 3 && NP == 2 && FUSED) {
+        if (halves) {                                  // every block of every lane is plain (the plan saw to that)
+            uint32_t ones = 0;
+            diag_halves_dna(V, P, ones, p, nxt, iters);
+            banked = 32u * (uint32_t)iters - ones;
+            above = kmax;                              // rows above the matrix were banked as zeros
+        }
+    }
+    for (int it = halves ? iters : 0; it < iters;) {
         if constexpr (NLW == 3 && NP == 2 && FUSED) {
             auto plain3 = [&](int i) { return i + 3 <= iters && __builtin_amdgcn_ballot_w64(i + 3 > plain_hi) == 0; };
             if (plain3(it)) {
@@ -487,7 +572,7 @@ k_llcs_diag(const uint32_t *__restrict__ rows, const uint32_t *__restrict__ tile
 
     if (pid != 0xffffffffu) {
         const int32_t d = (int32_t)(m + n - 2u * zeros);
-        if (d <= T) {
+        if (d <= (halves ? MALCS_DIAG_HALF_T : T)) {
             dist[pid] = d;
         } else {
             const uint32_t cls = kc >> 16;
@@ -543,18 +628,16 @@ int malcs_diag_plan(malcs_batch *b, int nlw, const std::vector<uint32_t> &pairs,
     const bool trim = b->raw_syms && !(getenv("MALCS_DIAG_TRIM") && atoi(getenv("MALCS_DIAG_TRIM")) == 0);
     const uint32_t min_rows = 32u * (2u * (uint32_t)nlw + 2u);
     const uint32_t NP = (uint32_t)b->n_planes;
-    struct item { uint32_t pid, kc, iters, po, to, m, n, q; };
+    struct item { uint32_t pid, delta, cls, iters, po, to, m, n, q, mt, nt; };
     std::vector<item> items(pairs.size());
-    std::atomic<uint64_t> cells_sum{0};
     std::atomic<uint32_t> misfit{0xffffffffu};
     auto plan_items = [&](size_t first, size_t last) {
-        uint64_t cells = 0;
         for (size_t i = first; i < last; i++) {
             const uint32_t pid = pairs[i];
             const bool a_short = b->a_len[pid] <= b->b_len[pid];
             uint32_t m = a_short ? b->a_len[pid] : b->b_len[pid], n = a_short ? b->b_len[pid] : b->a_len[pid];
             uint32_t po = a_short ? b->a_off[pid] : b->b_off[pid], to = a_short ? b->b_off[pid] : b->a_off[pid];
-            uint32_t q = 0;
+            uint32_t q = 0, mt = m, nt = n;
             const int delta = (int)(n - m);
             if (delta > T || n == 0) { misfit.store(pid); return; }
             if (trim && m > min_rows) {
@@ -578,17 +661,16 @@ int malcs_diag_plan(malcs_batch *b, int nlw, const std::vector<uint32_t> &pairs,
                     suf += 8;
                 }
                 while (suf < room - pre && xe[-1 - (ptrdiff_t)suf] == ye[-1 - (ptrdiff_t)suf]) suf++;
-                // a text of whole blocks has no masked last block: give back up to 31 of the cut symbols for that
-                const uint32_t ragged = (32u - ((n - pre - suf) & 31u)) & 31u;
-                if (ragged && ragged <= pre + suf) { const uint32_t back = std::min(ragged, suf); suf -= back; pre -= ragged - back; }
                 po += (pre >> 5) * NP; to += (pre >> 5) * NP; q = pre & 31u;
                 m -= pre + suf; n -= pre + suf;
+                mt = q + m + suf; nt = q + n + suf;
             }
-            const int kmax = delta + (T - delta) / 2;
-            items[i] = {pid, (uint32_t)kmax | ((uint32_t)retry_class[i] << 16), (n + 31u) / 32u, po, to, m, n, q};
-            cells += (uint64_t)(32 * nlw) * n;
+            // a text of whole blocks has no masked last block: both sequences grow by the same symbols at the end (what
+            // was cut off there first, symbol 0 beyond the end: see k_diag_layout)
+            const uint32_t ragged = (32u - (n & 31u)) & 31u;
+            m += ragged; n += ragged;
+            items[i] = {pid, (uint32_t)delta, retry_class[i], (n + 31u) / 32u, po, to, m, n, q, mt, nt};
         }
-        cells_sum += cells;
     };
     {
         // the scan of the ends is a cache miss or two per sequence: threads from a few thousand pairs on
@@ -603,7 +685,6 @@ int malcs_diag_plan(malcs_batch *b, int nlw, const std::vector<uint32_t> &pairs,
         for (std::thread &t : pool) t.join();
     }
     if (misfit.load() != 0xffffffffu) { malcs_set_error("pair %u does not fit the window class", misfit.load()); return MALCS_ERR_INTERNAL; }
-    const uint64_t cells = cells_sum.load();
     trace.lap("common ends");
     // tiles of equal length, and the pairs whose text is whole blocks together (their tiles never leave the plain path)
     // (a stable counting sort: key = whole blocks first, then the number of blocks)
@@ -620,7 +701,7 @@ int malcs_diag_plan(malcs_batch *b, int nlw, const std::vector<uint32_t> &pairs,
     }
     const uint32_t n_tiles = (uint32_t)((items.size() + 63) / 64);
     std::vector<uint32_t> tile_pid((size_t)n_tiles * 64, 0xffffffffu), tile_kc((size_t)n_tiles * 64, 0u);
-    std::vector<uint32_t> tile_seq((size_t)n_tiles * 64 * 5, 0u);          // po, to, m, n, q of every slot (five arrays back to back)
+    std::vector<uint32_t> tile_seq((size_t)n_tiles * 64 * 7, 0u);          // po, to, m, n, q, mt, nt of every slot (seven arrays back to back)
     const size_t slots = (size_t)n_tiles * 64;
     std::vector<uint32_t> tile_off(n_tiles + 1), tile_iters(n_tiles);
     // Which tile runs as which workgroup.  All workgroups of a launch are resident at once, and the dispatcher deals
@@ -630,6 +711,8 @@ int malcs_diag_plan(malcs_batch *b, int nlw, const std::vector<uint32_t> &pairs,
     // those with a free slot, SIMDs with fewer slots first: at C2 the 485 SIMDs with one wave get the longest tiles and
     // the others a long and a short one each.
     std::vector<uint32_t> tile_at(n_tiles);                    // workgroup index -> tile (in sorted order)
+    std::vector<uint8_t> tile_half(n_tiles, 0);
+    const bool half_mode = nlw == 3 && NP == 2 && getenv("MALCS_DIAG_HALF") && atoi(getenv("MALCS_DIAG_HALF")) != 0;
     {
         const uint32_t S = std::max(1, b->ctx->prop.multiProcessorCount) * 4u;
         struct simd_load { uint64_t load; uint32_t slots, used, idx; };
@@ -641,15 +724,24 @@ int malcs_diag_plan(malcs_batch *b, int nlw, const std::vector<uint32_t> &pairs,
         std::vector<simd_load> heap;
         for (uint32_t i = 0; i < std::min(S, n_tiles); i++) heap.push_back({0, (n_tiles - i + S - 1) / S, 0, i});
         std::make_heap(heap.begin(), heap.end(), worse);
-        // cost of a tile in sixteenths of a plain block: a last block with masked steps costs 1.6 plain ones
+        // cost of a tile in sixteenths of a three-limb block; a block in two-limb mode costs 0.74.  Two-limb mode
+        // (MALCS_DIAG_HALF=1): tiles whose lanes all have a length difference the narrower band holds.
         std::vector<std::pair<uint32_t, uint32_t>> by_cost(n_tiles);
         for (uint32_t j = 0; j < n_tiles; j++) {
-            uint32_t it = 1, ragged = 0;
-            for (size_t i = (size_t)j * 64; i < std::min(items.size(), (size_t)(j + 1) * 64); i++) {
-                it = std::max(it, items[i].iters);
-                ragged |= items[i].n & 31u;
+            const size_t i0 = (size_t)j * 64, i1 = std::min(items.size(), i0 + 64);
+            // the lanes of a tile run in step: the shorter texts of a tile grow to its longest by whole blocks (again the
+            // same symbols on both sequences), so that no lane has masked blocks while the others still work
+            uint32_t longest = 0;
+            for (size_t i = i0; i < i1; i++) longest = std::max(longest, items[i].n);
+            bool half = half_mode;
+            for (size_t i = i0; i < i1; i++) {
+                const uint32_t grow = longest - items[i].n;
+                items[i].m += grow; items[i].n += grow; items[i].iters = items[i].n / 32u;
+                half = half && items[i].delta <= (uint32_t)MALCS_DIAG_HALF_T;
             }
-            by_cost[j] = {16u * it + (ragged ? 10u : 0u), j};
+            const uint32_t it = std::max(1u, longest / 32u);
+            tile_half[j] = half;
+            by_cost[j] = {half ? 12u * it : 16u * it, j};
         }
         std::sort(by_cost.begin(), by_cost.end(), [](const std::pair<uint32_t, uint32_t> &x, const std::pair<uint32_t, uint32_t> &y) {
             return x.first != y.first ? x.first > y.first : x.second < y.second;
@@ -662,17 +754,21 @@ int malcs_diag_plan(malcs_batch *b, int nlw, const std::vector<uint32_t> &pairs,
             if (top.used == top.slots) heap.pop_back(); else std::push_heap(heap.begin(), heap.end(), worse);
         }
     }
-    uint64_t row = 0;
+    uint64_t row = 0, cells = 0;
     uint32_t max_rows = 0;
     for (uint32_t t = 0; t < n_tiles; t++) {
         uint32_t it = 1;
         const size_t j0 = (size_t)tile_at[t] * 64, s0 = (size_t)t * 64;
+        const bool half = tile_half[tile_at[t]];
+        const int Tm = half ? MALCS_DIAG_HALF_T : T;
         for (size_t i = j0; i < std::min(items.size(), j0 + 64); i++) {
             const size_t k = s0 + (i - j0);
-            tile_pid[k] = items[i].pid; tile_kc[k] = items[i].kc; it = std::max(it, items[i].iters);
-            tile_seq[k] = items[i].po; tile_seq[slots + k] = items[i].to; tile_seq[2 * slots + k] = items[i].m; tile_seq[3 * slots + k] = items[i].n; tile_seq[4 * slots + k] = items[i].q;
+            const int kmax = (int)items[i].delta + (Tm - (int)items[i].delta) / 2;
+            tile_pid[k] = items[i].pid; tile_kc[k] = (uint32_t)kmax | (items[i].cls << 16); it = std::max(it, items[i].iters);
+            tile_seq[k] = items[i].po; tile_seq[slots + k] = items[i].to; tile_seq[2 * slots + k] = items[i].m; tile_seq[3 * slots + k] = items[i].n; tile_seq[4 * slots + k] = items[i].q; tile_seq[5 * slots + k] = items[i].mt; tile_seq[6 * slots + k] = items[i].nt;
+            cells += (uint64_t)(half ? 64 : 32 * nlw) * items[i].n;
         }
-        tile_off[t] = (uint32_t)row; tile_iters[t] = it;
+        tile_off[t] = (uint32_t)row; tile_iters[t] = it | (half ? 0x80000000u : 0u);
         const uint32_t r = (uint32_t)(nlw - 1) + it;
         max_rows = std::max(max_rows, r);
         row += (uint64_t)META_ROWS + (uint64_t)(nlw - 1) * b->n_planes + (uint64_t)it * 2u * b->n_planes;
@@ -714,9 +810,9 @@ int malcs_diag_plan(malcs_batch *b, int nlw, const std::vector<uint32_t> &pairs,
     MALCS_HIP(hipMemsetAsync(d.d_retry_count, 0, 2 * ncls * sizeof(uint32_t), st));
     const dim3 grid(max_rows, n_tiles), block(64);
     switch (b->n_planes) {
-    case 2: hipLaunchKernelGGL(k_diag_layout<2>, grid, block, 0, st, b->d_planes, d_tile_seq, d_tile_seq + slots, d_tile_seq + 2 * slots, d_tile_seq + 3 * slots, d_tile_seq + 4 * slots, d_tile_pid, d_tile_kc, d.d_tile_off, d.d_tile_iters, nlw, d.d_rows); break;
-    case 3: hipLaunchKernelGGL(k_diag_layout<3>, grid, block, 0, st, b->d_planes, d_tile_seq, d_tile_seq + slots, d_tile_seq + 2 * slots, d_tile_seq + 3 * slots, d_tile_seq + 4 * slots, d_tile_pid, d_tile_kc, d.d_tile_off, d.d_tile_iters, nlw, d.d_rows); break;
-    case 4: hipLaunchKernelGGL(k_diag_layout<4>, grid, block, 0, st, b->d_planes, d_tile_seq, d_tile_seq + slots, d_tile_seq + 2 * slots, d_tile_seq + 3 * slots, d_tile_seq + 4 * slots, d_tile_pid, d_tile_kc, d.d_tile_off, d.d_tile_iters, nlw, d.d_rows); break;
+    case 2: hipLaunchKernelGGL(k_diag_layout<2>, grid, block, 0, st, b->d_planes, d_tile_seq, d_tile_seq + slots, d_tile_seq + 2 * slots, d_tile_seq + 3 * slots, d_tile_seq + 4 * slots, d_tile_seq + 5 * slots, d_tile_seq + 6 * slots, d_tile_pid, d_tile_kc, d.d_tile_off, d.d_tile_iters, nlw, d.d_rows); break;
+    case 3: hipLaunchKernelGGL(k_diag_layout<3>, grid, block, 0, st, b->d_planes, d_tile_seq, d_tile_seq + slots, d_tile_seq + 2 * slots, d_tile_seq + 3 * slots, d_tile_seq + 4 * slots, d_tile_seq + 5 * slots, d_tile_seq + 6 * slots, d_tile_pid, d_tile_kc, d.d_tile_off, d.d_tile_iters, nlw, d.d_rows); break;
+    case 4: hipLaunchKernelGGL(k_diag_layout<4>, grid, block, 0, st, b->d_planes, d_tile_seq, d_tile_seq + slots, d_tile_seq + 2 * slots, d_tile_seq + 3 * slots, d_tile_seq + 4 * slots, d_tile_seq + 5 * slots, d_tile_seq + 6 * slots, d_tile_pid, d_tile_kc, d.d_tile_off, d.d_tile_iters, nlw, d.d_rows); break;
     }
     MALCS_HIP(hipGetLastError());
     MALCS_HIP(malcs_sync(st));           // the host vectors above are locals
