@@ -202,9 +202,10 @@ class Batch:
         return ms.value
 
     def plan_info(self):
-        info = (ctypes.c_uint64 * 6)()
+        info = (ctypes.c_uint64 * 8)()
         check(lib.malcs_batch_plan_info(self.handle, info))
-        keys = ("window_pairs", "window_limbs", "window_threshold", "window_cells", "full_cells", "full_classes")
+        keys = ("window_pairs", "window_limbs", "window_threshold", "window_cells", "full_cells", "full_classes",
+                "window_tiles", "two_limb_tiles")
         return dict(zip(keys, (int(x) for x in info)))
 
     def lcs_nodes(self, shift=None, max_distance=None):

@@ -357,6 +357,7 @@ int malcs_batch_plan_info(const malcs_batch *b, uint64_t *info)
     if (!b || !info) { malcs_set_error("NULL argument"); return MALCS_ERR_ARG; }
     info[0] = b->diag.n_pairs; info[1] = (uint64_t)b->diag.nlw; info[2] = (uint64_t)b->diag.T;
     info[3] = b->diag.window_cells; info[4] = b->full_cells; info[5] = b->dist_buckets.size();
+    info[6] = b->diag.n_tiles; info[7] = b->diag.n_half_tiles;
     return MALCS_OK;
 }
 

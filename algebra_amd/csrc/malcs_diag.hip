@@ -604,13 +604,12 @@ int malcs_diag_threshold(int nlw) { return 32 * nlw - 32; }
 void malcs_diag_release(malcs_batch *b)
 {
     diag_plan &d = b->diag;
-    hipFree(d.d_rows); hipFree(d.d_tile_off); hipFree(d.d_tile_iters);
-    hipFree(d.d_retry_list); hipFree(d.d_retry_first); hipFree(d.d_retry_cap); hipFree(d.d_retry_count);
+    hipFree(d.d_rows);                   // the other arrays of the plan are parts of this allocation
     d = diag_plan();
 }
 
-int malcs_diag_plan(malcs_batch *b, int nlw, const std::vector<uint32_t> &pairs, const std::vector<uint8_t> &retry_class,
-                    const std::vector<diag_retry> &classes)
+static int plan_window(malcs_batch *b, int nlw, const std::vector<uint32_t> &pairs, const std::vector<uint8_t> &retry_class,
+                       const std::vector<diag_retry> &classes, bool half_mode)
 {
     diag_plan &d = b->diag;
     d = diag_plan();
@@ -712,7 +711,6 @@ int malcs_diag_plan(malcs_batch *b, int nlw, const std::vector<uint32_t> &pairs,
     // the others a long and a short one each.
     std::vector<uint32_t> tile_at(n_tiles);                    // workgroup index -> tile (in sorted order)
     std::vector<uint8_t> tile_half(n_tiles, 0);
-    const bool half_mode = nlw == 3 && NP == 2 && getenv("MALCS_DIAG_HALF") && atoi(getenv("MALCS_DIAG_HALF")) != 0;
     {
         const uint32_t S = std::max(1, b->ctx->prop.multiProcessorCount) * 4u;
         struct simd_load { uint64_t load; uint32_t slots, used, idx; };
@@ -785,19 +783,23 @@ int malcs_diag_plan(malcs_batch *b, int nlw, const std::vector<uint32_t> &pairs,
     for (size_t c = 0; c < classes.size(); c++) { first[c] = acc; acc += cap[c]; d.retry[c].first = first[c]; d.retry[c].cap = cap[c]; }
 
     hipStream_t st = b->ctx->stream;
-    dev_scoped<uint32_t> tile_pid_dev, tile_kc_dev, tile_seq_dev;
-    uint32_t *&d_tile_pid = tile_pid_dev.p, *&d_tile_kc = tile_kc_dev.p, *&d_tile_seq = tile_seq_dev.p;
     const size_t ncls = std::max<size_t>(classes.size(), 1);
-    MALCS_HIP(hipMalloc(&d.d_rows, ((size_t)row + 2u * b->n_planes) * 64u * sizeof(uint32_t)));   // + one block of padding: the kernel prefetches unconditionally
-    MALCS_HIP(hipMalloc(&d.d_tile_off, (n_tiles + 1) * sizeof(uint32_t)));
-    MALCS_HIP(hipMalloc(&d.d_tile_iters, n_tiles * sizeof(uint32_t)));
-    MALCS_HIP(hipMalloc(&d.d_retry_list, (size_t)std::max<uint32_t>(acc, 1) * sizeof(uint32_t)));
-    MALCS_HIP(hipMalloc(&d.d_retry_first, ncls * sizeof(uint32_t)));
-    MALCS_HIP(hipMalloc(&d.d_retry_cap, ncls * sizeof(uint32_t)));
-    MALCS_HIP(hipMalloc(&d.d_retry_count, 2 * ncls * sizeof(uint32_t)));   // two sets, used by alternate launches
-    MALCS_HIP(hipMalloc(&d_tile_pid, tile_pid.size() * sizeof(uint32_t)));
-    MALCS_HIP(hipMalloc(&d_tile_kc, tile_kc.size() * sizeof(uint32_t)));
-    MALCS_HIP(hipMalloc(&d_tile_seq, tile_seq.size() * sizeof(uint32_t)));
+    // one allocation for everything that lives as long as the plan, one for what only the layout kernel reads
+    // (an allocation costs a fraction of a millisecond; dwords, every array on a 256-byte boundary)
+    size_t keep = 0, temp = 0;
+    auto carve = [](size_t &total, size_t dwords) { const size_t at = total; total += (dwords + 63) & ~(size_t)63; return at; };
+    const size_t at_rows = carve(keep, ((size_t)row + 2u * b->n_planes) * 64u);     // + one block of padding: the kernel prefetches unconditionally
+    const size_t at_off = carve(keep, n_tiles + 1), at_iters = carve(keep, n_tiles);
+    const size_t at_list = carve(keep, std::max<uint32_t>(acc, 1)), at_first = carve(keep, ncls), at_cap = carve(keep, ncls);
+    const size_t at_count = carve(keep, 2 * ncls);                                  // two sets, used by alternate launches
+    const size_t at_pid = carve(temp, tile_pid.size()), at_kc = carve(temp, tile_kc.size()), at_seq = carve(temp, tile_seq.size());
+    MALCS_HIP(hipMalloc(&d.d_rows, keep * sizeof(uint32_t)));
+    d.d_tile_off = d.d_rows + at_off; d.d_tile_iters = d.d_rows + at_iters; d.d_retry_list = d.d_rows + at_list;
+    d.d_retry_first = d.d_rows + at_first; d.d_retry_cap = d.d_rows + at_cap; d.d_retry_count = d.d_rows + at_count;
+    (void)at_rows;                                                                  // the rows come first: d_rows is the allocation
+    dev_scoped<uint32_t> temp_dev;
+    MALCS_HIP(hipMalloc(&temp_dev.p, temp * sizeof(uint32_t)));
+    uint32_t *const d_tile_pid = temp_dev.p + at_pid, *const d_tile_kc = temp_dev.p + at_kc, *const d_tile_seq = temp_dev.p + at_seq;
     MALCS_HIP(malcs_h2d(st, d.d_tile_off, tile_off.data(), (n_tiles + 1) * sizeof(uint32_t)));
     MALCS_HIP(malcs_h2d(st, d.d_tile_iters, tile_iters.data(), n_tiles * sizeof(uint32_t)));
     MALCS_HIP(malcs_h2d(st, d_tile_pid, tile_pid.data(), tile_pid.size() * sizeof(uint32_t)));
@@ -818,7 +820,45 @@ int malcs_diag_plan(malcs_batch *b, int nlw, const std::vector<uint32_t> &pairs,
     MALCS_HIP(malcs_sync(st));           // the host vectors above are locals
     trace.lap("allocations, copies, layout kernel");
     d.nlw = nlw; d.T = T; d.n_tiles = n_tiles; d.n_pairs = (uint32_t)pairs.size(); d.window_cells = cells;
+    for (uint32_t j = 0; j < n_tiles; j++) d.n_half_tiles += tile_half[j];
     return MALCS_OK;
+}
+
+// The window class of a batch.  Three limbs (T = 64) unless the batch is similar enough for two (T = 48, a quarter less
+// work): MALCS_DIAG_HALF=0 / 1 decides by hand; otherwise a sample of about a thousand pairs is planned and run on its
+// own, and two limbs it is when none of the sampled distances comes near the threshold -- whatever exceeds it would be
+// redone over the full matrix, at ten times the cost of a window.
+int malcs_diag_plan(malcs_batch *b, int nlw, const std::vector<uint32_t> &pairs, const std::vector<uint8_t> &retry_class,
+                    const std::vector<diag_retry> &classes)
+{
+    bool half_mode = false;
+    if (nlw == 3 && b->n_planes == 2 && !pairs.empty()) {
+        const char *env = getenv("MALCS_DIAG_HALF");
+        if (env && *env) {
+            half_mode = atoi(env) != 0;
+        } else if (pairs.size() >= 4096) {
+            malcs_stage_trace trace("window plan");
+            const size_t stride = pairs.size() / 1024;
+            std::vector<uint32_t> sample;
+            std::vector<uint8_t> sample_class;
+            for (size_t i = stride / 2; i < pairs.size(); i += stride) { sample.push_back(pairs[i]); sample_class.push_back(retry_class[i]); }
+            int rc = plan_window(b, nlw, sample, sample_class, classes, false);
+            if (rc) return rc;
+            hipStream_t st = b->ctx->stream;
+            std::vector<int32_t> dist(b->n_pairs);
+            MALCS_HIP(hipMemsetAsync(b->d_dist, 0xff, b->n_pairs * sizeof(int32_t), st));      // -1: the window did not settle the pair
+            rc = malcs_diag_launch(b, true);
+            if (rc) return rc;
+            MALCS_HIP(malcs_d2h(st, dist.data(), b->d_dist, b->n_pairs * sizeof(int32_t)));
+            MALCS_HIP(malcs_sync(st));
+            malcs_diag_release(b);
+            int32_t worst = 0;
+            for (uint32_t pid : sample) worst = std::max(worst, dist[pid] < 0 ? 0x7fffffff : dist[pid]);
+            half_mode = worst <= MALCS_DIAG_HALF_T - 6;
+            trace.lap(half_mode ? "sample: two limbs" : "sample: three limbs");
+        }
+    }
+    return plan_window(b, nlw, pairs, retry_class, classes, half_mode);
 }
 
 // Launches the window kernel.  The retry counters exist twice: a launch appends through one set and zeroes

@@ -85,9 +85,9 @@ struct diag_retry {        // pairs the window could not settle go back to their
 struct diag_plan {
     int nlw = 0;                         // limbs in the window (0: no window class in this batch)
     int T = 0;                           // results <= T are exact
-    uint32_t n_tiles = 0, n_pairs = 0;
+    uint32_t n_tiles = 0, n_pairs = 0, n_half_tiles = 0;   // n_half_tiles: tiles in two-limb mode (T = 48)
     uint64_t window_cells = 0;           // sum over the class of 32 * nlw * (text length)
-    uint32_t *d_rows = nullptr;          // tiles of 64 pairs, lane-interleaved rows of 64 dwords
+    uint32_t *d_rows = nullptr;          // tiles of 64 pairs, lane-interleaved rows of 64 dwords; the allocation the arrays below are parts of
     uint32_t *d_tile_off = nullptr;      // first row of each tile
     uint32_t *d_tile_iters = nullptr;    // column blocks of each tile
     uint32_t *d_retry_list = nullptr, *d_retry_first = nullptr, *d_retry_cap = nullptr, *d_retry_count = nullptr;

@@ -249,8 +249,10 @@ def main():
     if plan["window_pairs"]:
         kernel_cells = float(plan["window_cells"])
         kernel_name = f"k_llcs_diag<{plan['window_limbs']},2,true>"
+        rows = (f"64 rows (two-limb mode, {plan['two_limb_tiles']} of {plan['window_tiles']} tiles; the others "
+                f"{32 * plan['window_limbs']})" if plan["two_limb_tiles"] else f"{32 * plan['window_limbs']} rows")
         algorithmic = (f"{OPS_PER_CELL} lane-op/cell x {kernel_cells:.4g} window cells/launch "
-                       f"({32 * plan['window_limbs']} rows x text length without the pair's common ends, {plan['window_pairs']} pairs; "
+                       f"({rows} x text length without the pair's common ends, {plan['window_pairs']} pairs; "
                        f"{cells:.4g} full-matrix-equivalent cells)")
     else:
         kernel_cells = cells

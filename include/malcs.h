@@ -93,8 +93,9 @@ int malcs_edit_distance_time(malcs_batch *batch, int iters, float *ms_total);
  * info[0] pairs in the window class, [1] limbs (32 rows each) in the window, [2] its threshold T
  * (results <= T are final, others are redone over the full matrix), [3] cells the window class computes
  * = sum 32 * limbs * max(m, n), [4] full-matrix cells of the whole batch = sum m * n,
- * [5] number of full-matrix launch classes. */
-int malcs_batch_plan_info(const malcs_batch *batch, uint64_t *info6);
+ * [5] number of full-matrix launch classes, [6] tiles (64 pairs) of the window class, [7] of those, tiles in two-limb
+ * mode (64 rows, threshold 48: chosen when a sample of the batch's distances stays well below it). */
+int malcs_batch_plan_info(const malcs_batch *batch, uint64_t *info8);
 /* As _time, but only the batch's dominant kernel (the window kernel when the batch has a window class,
  * else the full-matrix launches), so that its duration can be set against rocprofv3's. */
 int malcs_edit_distance_time_kernel(malcs_batch *batch, int iters, float *ms_total);

@@ -224,6 +224,38 @@ def test_edit_distance_window_class_mixed_tiles(native):
     assert np.array_equal(got, ref)
 
 
+@pytest.mark.parametrize("half", ["0", "1", ""])
+def test_edit_distance_two_limb_mode(native, half, monkeypatch):
+    """The two-limb mode of the window class (threshold 48): forced on, forced off and chosen from a sample of the
+    batch, on batches whose distances stay below the threshold, straddle it and exceed it."""
+    from oracle import oracle as O
+    if half:
+        monkeypatch.setenv("MALCS_DIAG_HALF", half)
+    else:
+        monkeypatch.delenv("MALCS_DIAG_HALF", raising=False)
+    for pairs, length, p, seed in [(6000, 1000, 0.01, 21), (6000, 1000, 0.02, 22), (5000, 700, 0.04, 23), (5000, 600, 0.0, 24)]:
+        data = gen.c2_batch(pairs, seed=seed, length=length, p=p)
+        batch = native.Batch(native.default_context(), *data, n_symbols=4)
+        info = batch.plan_info()
+        got = batch.distances()
+        again = batch.distances()
+        batch.close()
+        ref = O.edit_distance_batch(*data)
+        assert np.array_equal(got, ref) and np.array_equal(again, ref)
+        assert info["window_tiles"] > 0
+        if half == "1":
+            assert info["two_limb_tiles"] == info["window_tiles"]
+        elif half == "0":
+            assert info["two_limb_tiles"] == 0
+        else:                                       # the sample decides: similar batches only
+            assert (info["two_limb_tiles"] > 0) == (int(ref.max()) <= 42), (p, int(ref.max()), info)
+    data = gen.window_mix(5000, seed=12)
+    batch = native.Batch(native.default_context(), *data, n_symbols=4)
+    got = batch.distances()
+    batch.close()
+    assert np.array_equal(got, O.edit_distance_batch(*data))
+
+
 def test_empty_batch_and_bad_arguments(native):
     import algebra_amd
     assert algebra_amd.edit_distance_batch([]).tolist() == []
