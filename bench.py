@@ -101,6 +101,16 @@ def extra_configs(ctx, _native, gen):
                                     "GCUPS": round(fc / (ms * 1e-3) / 1e9, 1),
                                     "roofline_frac": round(fc * OPS_PER_CELL / (ms * 1e-3) / PEAK_LANE_OPS, 4)}
     full.close()
+    # ... and through the window class with three limbs for every tile (what a less similar batch gets: T = 64)
+    os.environ["MALCS_DIAG_HALF"] = "0"
+    three = _native.Batch(ctx, *gen.c2_batch(100000, seed=2), 4)
+    del os.environ["MALCS_DIAG_HALF"]
+    three.time_dominant_kernel(20)
+    ms = three.time_dominant_kernel(200) / 200
+    wc = float(three.plan_info()["window_cells"])
+    out["c2_three_limb_window"] = {"kernel": "k_llcs_diag<3,2,true>, no tile in two-limb mode", "kernel_ms": round(ms, 4),
+                                   "window_cells": wc, "roofline_frac": round(wc * OPS_PER_CELL / (ms * 1e-3) / PEAK_LANE_OPS, 4)}
+    three.close()
     n = 100000
     batch = _native.Batch(ctx, *gen.c2_batch(n, seed=12), 4)
     batch.graphs().close()                                     # warm-up
