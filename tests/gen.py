@@ -208,7 +208,7 @@ def c2_batch(n_pairs, seed=2, length=1000, p=0.01):
     return syms, a_off, np.full(n_pairs, length, np.uint32), b_off, b_len
 
 
-def window_mix(n_pairs, seed=7):
+def window_mix(n_pairs, seed=7, nsym=4):
     """Pairs for the window class of family 1 with mixed lengths (200 ... 4 000), indel rates (0 ... 4 %) and
     length differences (0 ... 60 on either end), either side first: tiles then mix lanes whose masked first /
     last blocks and plain stretches differ.  Flat arrays like c2_batch."""
@@ -216,14 +216,14 @@ def window_mix(n_pairs, seed=7):
     seqs = []
     for _ in range(n_pairs):
         length = int(rng.choice([rng.integers(200, 420), rng.integers(900, 1100), rng.integers(200, 4000)]))
-        a = rng.integers(0, 4, length).astype(np.uint8)
+        a = rng.integers(0, nsym, length).astype(np.uint8)
         p = float(rng.choice([0.0, 0.002, 0.01, 0.02, 0.04]))
         keep = rng.random(length) >= p
         ins = rng.random(length) < p
-        b = np.stack([np.where(ins, rng.integers(0, 4, length), 255).astype(np.uint8),
+        b = np.stack([np.where(ins, rng.integers(0, nsym, length), 255).astype(np.uint8),
                       np.where(keep, a, 255).astype(np.uint8)], 1).reshape(-1)
         b = b[b != 255]
-        pad = rng.integers(0, 4, int(rng.choice([0, 0, 1, 5, 31, 32, 33, 60]))).astype(np.uint8)
+        pad = rng.integers(0, nsym, int(rng.choice([0, 0, 1, 5, 31, 32, 33, 60]))).astype(np.uint8)
         side = rng.integers(0, 3)
         b = np.concatenate([pad, b]) if side == 0 else (np.concatenate([b, pad]) if side == 1 else b)
         seqs.append((a, b) if rng.random() < 0.5 else (b, a))

@@ -209,12 +209,13 @@ def test_edit_distance_window_class(native, nlw, nsym, monkeypatch):
         assert (ref > 32 * nlw - 32).sum() > 50 and (ref <= 32 * nlw - 32).sum() > 50
 
 
-def test_edit_distance_window_class_mixed_tiles(native):
+@pytest.mark.parametrize("nsym", [4, 7, 13])
+def test_edit_distance_window_class_mixed_tiles(native, nsym):
     """Tiles of the default window class whose lanes differ in length, length difference and divergence: the
     three-block statement of the plain stretch, the masked first / last blocks and the retry list in one batch."""
     from oracle import oracle as O
-    data = gen.window_mix(6000, seed=11)
-    batch = native.Batch(native.default_context(), *data, n_symbols=4)
+    data = gen.window_mix(6000, seed=11 + nsym, nsym=nsym)
+    batch = native.Batch(native.default_context(), *data, n_symbols=nsym)
     info = batch.plan_info()
     got = batch.distances()
     batch.close()

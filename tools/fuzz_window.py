@@ -1,6 +1,6 @@
 """Window class of family 1 against the oracle on pairs of mixed lengths, length differences and indel rates, so that
 tiles mix lanes whose plain stretches (malcs_diag.hip: three-block statement) start and end in different blocks
-(dev tool).  python tools/fuzz_window.py [pairs] [seed]"""
+(dev tool).  python tools/fuzz_window.py [pairs] [seed] [symbols]"""
 import sys
 sys.path.insert(0, "."); sys.path.insert(0, "tests")
 import numpy as np
@@ -9,10 +9,11 @@ from algebra_amd import _native as N
 from oracle import oracle as O
 
 n_pairs = int(sys.argv[1]) if len(sys.argv) > 1 else 20000
-data = gen.window_mix(n_pairs, int(sys.argv[2]) if len(sys.argv) > 2 else 7)
+nsym = int(sys.argv[3]) if len(sys.argv) > 3 else 4
+data = gen.window_mix(n_pairs, int(sys.argv[2]) if len(sys.argv) > 2 else 7, nsym)
 lens = np.stack([data[2], data[4]], 1)
 ctx = N.Context(0)
-b = N.Batch(ctx, *data, 4)
+b = N.Batch(ctx, *data, nsym)
 info = b.plan_info()
 d = b.distances()
 ref = O.edit_distance_batch(*data)
