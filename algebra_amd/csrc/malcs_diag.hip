@@ -685,17 +685,15 @@ static int plan_window(malcs_batch *b, int nlw, const std::vector<uint32_t> &pai
     }
     if (misfit.load() != 0xffffffffu) { malcs_set_error("pair %u does not fit the window class", misfit.load()); return MALCS_ERR_INTERNAL; }
     trace.lap("common ends");
-    // tiles of equal length, and the pairs whose text is whole blocks together (their tiles never leave the plain path)
-    // (a stable counting sort: key = whole blocks first, then the number of blocks)
+    // tiles of equal length: a stable counting sort by the number of blocks
     {
         uint32_t max_it = 0;
         for (const item &x : items) max_it = std::max(max_it, x.iters);
-        auto key_of = [&](const item &x) -> size_t { return ((x.n & 31u) ? (size_t)max_it + 1 : 0) + x.iters; };
-        std::vector<size_t> start(2 * ((size_t)max_it + 1) + 1, 0);
-        for (const item &x : items) start[key_of(x) + 1]++;
+        std::vector<size_t> start((size_t)max_it + 2, 0);
+        for (const item &x : items) start[(size_t)x.iters + 1]++;
         for (size_t k = 1; k < start.size(); k++) start[k] += start[k - 1];
         std::vector<item> sorted(items.size());
-        for (const item &x : items) sorted[start[key_of(x)]++] = x;
+        for (const item &x : items) sorted[start[x.iters]++] = x;
         items.swap(sorted);
     }
     const uint32_t n_tiles = (uint32_t)((items.size() + 63) / 64);
