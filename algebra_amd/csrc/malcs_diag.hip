@@ -819,6 +819,7 @@ static int plan_window(malcs_batch *b, int nlw, const std::vector<uint32_t> &pai
     trace.lap("allocations, copies, layout kernel");
     d.nlw = nlw; d.T = T; d.n_tiles = n_tiles; d.n_pairs = (uint32_t)pairs.size(); d.window_cells = cells;
     for (uint32_t j = 0; j < n_tiles; j++) d.n_half_tiles += tile_half[j];
+    if (d.n_half_tiles == n_tiles) d.T = MALCS_DIAG_HALF_T;    // what the plan reports: the threshold of every tile
     return MALCS_OK;
 }
 

@@ -91,7 +91,7 @@ int malcs_edit_distance_time(malcs_batch *batch, int iters, float *ms_total);
 
 /* What the planner decided for this batch (for reports; bench.py prices its roofline with it):
  * info[0] pairs in the window class, [1] limbs (32 rows each) in the window, [2] its threshold T
- * (results <= T are final, others are redone over the full matrix), [3] cells the window class computes
+ * (results <= T are final, others are redone over the full matrix; 48 when every tile runs in two-limb mode), [3] cells the window class computes
  * = sum 32 * limbs * max(m, n), [4] full-matrix cells of the whole batch = sum m * n,
  * [5] number of full-matrix launch classes, [6] tiles (64 pairs) of the window class, [7] of those, tiles in two-limb
  * mode (64 rows, threshold 48: chosen when a sample of the batch's distances stays well below it). */
