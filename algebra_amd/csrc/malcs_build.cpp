@@ -459,6 +459,7 @@ static int graph_batch(malcs_batch *b, const int64_t *shift, const int64_t *max_
     malcs_ctx *ctx = b->ctx;
     hipStream_t st = ctx->stream;
     const uint64_t N = b->n_pairs;
+    malcs_stage_trace stages("lcs_graph_batch");
     out->g.resize(N);
     std::vector<event_span> pair_events(N);
     std::deque<std::vector<event>> event_store;          // one buffer per chunk, alive until the graphs are built
@@ -516,6 +517,7 @@ static int graph_batch(malcs_batch *b, const int64_t *shift, const int64_t *max_
         }
     }
 
+    stages.lap("distances");
     // launch classes.  Short windows keep all their row groups resident (L lanes per pair, several pairs per
     // wave); longer ones get a wave each whose 64 lanes slide along the band given by the distance.
     const int band_wmax = malcs_graph_max_band_words(b->n_planes);
@@ -578,6 +580,7 @@ static int graph_batch(malcs_batch *b, const int64_t *shift, const int64_t *max_
     MALCS_HIP(hipMemGetInfo(&free_b, &total_b));
     const uint64_t budget_dwords = std::min<uint64_t>(free_b / 2, 64ull << 30) / 4;
 
+    stages.lap("launch classes");
     for (int shape = 0; shape < 2; shape++) {
         sweep_set &S = sweeps[shape];
         if (S.pairs.empty()) continue;
@@ -587,6 +590,7 @@ static int graph_batch(malcs_batch *b, const int64_t *shift, const int64_t *max_
         ms_fwd += ms[0]; ms_reach += ms[1];
         for (size_t s = 0; s < S.pairs.size(); s++) sweep_slot[S.pairs[s]] = s;
     }
+    stages.lap("sweeps");
     dev_buf<uint32_t> d_work, d_evcap, d_evcnt, d_scratch;
     dev_buf<uint64_t> d_scoff, d_evoff, d_outoff;
     dev_buf<int32_t> d_kmin, d_kmax, d_rw, d_llcs, d_fdist;
@@ -708,6 +712,7 @@ static int graph_batch(malcs_batch *b, const int64_t *shift, const int64_t *max_
     }
     out->timing[0] = ms_fwd;
     out->timing[1] = ms_reach;
+    stages.lap("bit-vector classes");
 
     // ---- host: runs, ordering, graph compression (threads over pairs) ----
     const double t0 = now_ms();
@@ -765,6 +770,7 @@ static int graph_batch(malcs_batch *b, const int64_t *shift, const int64_t *max_
     worker(&out->stores[0]);
     for (std::thread &t : pool) t.join();
     out->timing[2] = (float)(now_ms() - t0);
+    stages.lap("host build");
     if (trace) fprintf(stderr, "malcs host build: %llu pairs, %u threads, wall %.2f ms; summed over threads: events->runs %.2f ms, build_graph %.2f ms\n",
                        (unsigned long long)N, nt, out->timing[2], ns_runs.load() / 1e6, ns_build.load() / 1e6);
     if (failed.load()) { malcs_set_error("device events do not form runs (internal error)"); return MALCS_ERR_INTERNAL; }
