@@ -479,8 +479,10 @@ int malcs_sweep_runs(malcs_batch *b, const std::vector<uint32_t> &work, const in
     hipStream_t st = b->ctx->stream;
     out_first.assign(work.size() + 1, 0);
     out_runs.clear();
+    malcs_stage_trace stages("sweep runs");
     size_t free_b = 0, total_b = 0;
     MALCS_HIP(hipMemGetInfo(&free_b, &total_b));
+    stages.lap("memory info");
     const uint64_t budget = std::min<uint64_t>(free_b / 4, 16ull << 30);      // bytes of runs per chunk
     size_t pos = 0;
     while (pos < work.size()) {
@@ -646,8 +648,10 @@ int malcs_sweep_optimal_runs(malcs_batch *b, bool small, const std::vector<uint3
     malcs_ctx *ctx = b->ctx;
     out_first.assign(work.size() + 1, 0);
     out_runs.clear();
+    malcs_stage_trace stages("sweep runs");
     size_t free_b = 0, total_b = 0;
     MALCS_HIP(hipMemGetInfo(&free_b, &total_b));
+    stages.lap("memory info");
     const uint64_t budget = std::min<uint64_t>(free_b / 2, 64ull << 30) / 4;  // ints of table per chunk
     size_t pos = 0;
     while (pos < work.size()) {
@@ -682,6 +686,7 @@ int malcs_sweep_optimal_runs(malcs_batch *b, bool small, const std::vector<uint3
             malcs_set_error("device allocation failed (sweep chunk of %u pairs, %llu MiB of reach table)", cnt, (unsigned long long)(tab_total >> 18));
             return MALCS_ERR_NOMEM;
         }
+        stages.lap("chunk, allocations");
         MALCS_HIP(malcs_h2d(st, d_work.p, work.data() + pos, cnt * 4ull));
         MALCS_HIP(malcs_h2d(st, d_dists.p, dists.data(), cnt * 4ull));
         MALCS_HIP(malcs_h2d(st, d_tab_off.p, tab_off.data(), cnt * 8ull));
@@ -699,6 +704,7 @@ int malcs_sweep_optimal_runs(malcs_batch *b, bool small, const std::vector<uint3
         float t = 0;
         MALCS_HIP(hipEventElapsedTime(&t, ctx->ev0, ctx->ev1));
         ms[0] += t;
+        stages.lap("backward sweep");
         // the pairs that go on to the forward pass (all of them when the distances were known)
         const uint32_t all = cnt;
         std::vector<uint32_t> keep, fwd_work;
@@ -759,12 +765,14 @@ int malcs_sweep_optimal_runs(malcs_batch *b, bool small, const std::vector<uint3
             total = 0;                                                        // the counts are exact: size every region to its count, redo
             for (uint32_t s = 0; s < cntf; s++) { cap[s] = std::max(cap[s], got[s]); off[s] = total; total += cap[s]; }
         }
+        stages.lap("forward sweep");
         // gather the used parts on the device, bring them home in one copy
         size_t base = out_runs.size();
         std::vector<uint64_t> packed_off(cntf);
         uint64_t kept = 0;
         for (uint32_t s = 0; s < cntf; s++) { packed_off[s] = kept; kept += got[s]; }
         out_runs.resize(base + kept * 4);
+        stages.lap("host vector for the runs");
         if (kept) {
             dbuf<uint4> d_packed;
             dbuf<uint64_t> d_packed_off;
@@ -774,6 +782,7 @@ int malcs_sweep_optimal_runs(malcs_batch *b, bool small, const std::vector<uint3
             if (rc) return rc;
             MALCS_HIP(malcs_d2h(st, out_runs.data() + base, d_packed.p, kept * 16ull));
             MALCS_HIP(malcs_sync(st));
+            stages.lap("compaction, runs to the host");
         }
         {
             uint64_t last = base >> 2;                                        // a pair without runs ends where its predecessor ends
