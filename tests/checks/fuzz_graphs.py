@@ -1,4 +1,4 @@
-"""Seeded fuzz of the graph paths against the oracle (dev tool): python tools/fuzz_graphs.py [pairs] [seed]."""
+"""Seeded fuzz of the graph paths against the oracle (dev tool): python tests/checks/fuzz_graphs.py [pairs] [seed]."""
 import os, sys, time
 sys.path.insert(0, "."); sys.path.insert(0, "tests")
 import numpy as np

@@ -1,6 +1,6 @@
 """Window class of family 1 against the oracle on pairs of mixed lengths, length differences and indel rates, so that
 tiles mix lanes whose plain stretches (malcs_diag.hip: three-block statement) start and end in different blocks
-(dev tool).  python tools/fuzz_window.py [pairs] [seed] [symbols]"""
+(dev tool).  python tests/checks/fuzz_window.py [pairs] [seed] [symbols]"""
 import sys
 sys.path.insert(0, "."); sys.path.insert(0, "tests")
 import numpy as np
