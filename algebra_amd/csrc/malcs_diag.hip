@@ -357,8 +357,8 @@ __device__ __forceinline__ void diag_triples_dna3(uint32_t (&V)[3], uint32_t (&P
             TG_BLOCK(TG_LC, TG_LA, TG_LB)
             TG_BANK(TG_LC)
             "s_waitcnt vmcnt(0)"
-            : "+v"(V0), "+v"(V1), "=v"(V2), "+v"(P00), "+v"(P01), "+v"(P10), "+v"(P11), "=v"(P20), "=v"(P21),
-              [w0] "=v"(w0), [w1] "=v"(w1), [bank] "+v"(bank), [n0] "+v"(n0), [n1] "+v"(n1), [n2] "+v"(n2), [n3] "+v"(n3)
+            : "+v"(V0), "+v"(V1), "=&v"(V2), "+v"(P00), "+v"(P01), "+v"(P10), "+v"(P11), "=&v"(P20), "=&v"(P21),
+              [w0] "=&v"(w0), [w1] "=&v"(w1), [bank] "+v"(bank), [n0] "+v"(n0), [n1] "+v"(n1), [n2] "+v"(n2), [n3] "+v"(n3)
             : [np] "v"(p)
             : "v22", "v26", "v30", "v23", "v27", "v31", "v35", "v47", "v39", "v51", "v43", "v55",
               "s40", "s41", "s42", "s43", "s44", "s45", "s46", "s47", "s48", "s49");
@@ -425,8 +425,8 @@ __device__ __forceinline__ void diag_halves_dna(uint32_t (&V)[3], uint32_t (&P)[
             HG_DOWN
             "v_mov_b32 v21, v25\n\tv_mov_b32 v33, v37\n\tv_mov_b32 v25, v29\n\tv_mov_b32 v37, v41\n\t"
             "s_waitcnt vmcnt(0)"
-            : "+v"(V0), "+v"(V1), "+v"(P00), "+v"(P01), "+v"(P10), "+v"(P11), "=v"(P20), "=v"(P21),
-              [w0] "=v"(w0), [w1] "=v"(w1), [bank] "+v"(bank), [n0] "+v"(n0), [n1] "+v"(n1), [n2] "+v"(n2), [n3] "+v"(n3)
+            : "+v"(V0), "+v"(V1), "+v"(P00), "+v"(P01), "+v"(P10), "+v"(P11), "=&v"(P20), "=&v"(P21),
+              [w0] "=&v"(w0), [w1] "=&v"(w1), [bank] "+v"(bank), [n0] "+v"(n0), [n1] "+v"(n1), [n2] "+v"(n2), [n3] "+v"(n3)
             : [np] "v"(p)
             : "v22", "v26", "v23", "v27", "v35", "v47", "v39", "v51", "v45", "v49", "v53", "v57",
               "s40", "s41", "s42", "s43", "s44", "s45", "s46", "s47", "s48", "s49");
