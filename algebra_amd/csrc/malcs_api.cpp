@@ -96,6 +96,34 @@ hipError_t malcs_sync(hipStream_t st)
     return c ? drain(c) : hipStreamSynchronize(st);
 }
 
+// everything a context owns, released in reverse order of creation (also on the error paths of malcs_ctx_create)
+static void ctx_release(malcs_ctx *c)
+{
+    if (c->stage) hipHostFree(c->stage);
+    if (c->ev0) hipEventDestroy(c->ev0);
+    if (c->ev1) hipEventDestroy(c->ev1);
+    if (c->ev2) hipEventDestroy(c->ev2);
+    if (c->stream) hipStreamDestroy(c->stream);
+    delete c;
+}
+
+static int ctx_setup(malcs_ctx *c)
+{
+    MALCS_HIP(hipSetDevice(c->device));
+    MALCS_HIP(hipGetDeviceProperties(&c->prop, c->device));
+    if (strncmp(c->prop.gcnArchName, "gfx950", 6) != 0) {
+        malcs_set_error("device %d is %s; libmalcs is built for gfx950 only", c->device, c->prop.gcnArchName);
+        return MALCS_ERR_HIP;
+    }
+    MALCS_HIP(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
+    MALCS_HIP(hipEventCreate(&c->ev0));
+    MALCS_HIP(hipEventCreate(&c->ev1));
+    MALCS_HIP(hipEventCreate(&c->ev2));
+    if (hipHostMalloc((void **)&c->stage, STAGE_BYTES, hipHostMallocDefault) == hipSuccess) c->stage_cap = STAGE_BYTES;
+    else { c->stage = nullptr; (void)hipGetLastError(); }        // no staging: copies go straight from pageable memory
+    return MALCS_OK;
+}
+
 extern "C" {
 
 int malcs_ctx_create(int device, malcs_ctx **out)
@@ -113,19 +141,8 @@ int malcs_ctx_create(int device, malcs_ctx **out)
     malcs_ctx *c = new (std::nothrow) malcs_ctx();
     if (!c) { malcs_set_error("out of host memory"); return MALCS_ERR_NOMEM; }
     c->device = device;
-    MALCS_HIP(hipSetDevice(device));
-    MALCS_HIP(hipGetDeviceProperties(&c->prop, device));
-    if (strncmp(c->prop.gcnArchName, "gfx950", 6) != 0) {
-        malcs_set_error("device %d is %s; libmalcs is built for gfx950 only", device, c->prop.gcnArchName);
-        delete c;
-        return MALCS_ERR_HIP;
-    }
-    MALCS_HIP(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
-    MALCS_HIP(hipEventCreate(&c->ev0));
-    MALCS_HIP(hipEventCreate(&c->ev1));
-    MALCS_HIP(hipEventCreate(&c->ev2));
-    if (hipHostMalloc((void **)&c->stage, STAGE_BYTES, hipHostMallocDefault) == hipSuccess) c->stage_cap = STAGE_BYTES;
-    else { c->stage = nullptr; (void)hipGetLastError(); }        // no staging: copies go straight from pageable memory
+    const int rc = ctx_setup(c);
+    if (rc) { ctx_release(c); return rc; }
     {
         std::lock_guard<std::mutex> lock(g_ctx_mutex);
         g_ctxs.push_back(c);
@@ -143,12 +160,7 @@ int malcs_ctx_destroy(malcs_ctx *c)
         std::lock_guard<std::mutex> lock(g_ctx_mutex);
         for (size_t i = 0; i < g_ctxs.size(); i++) if (g_ctxs[i] == c) { g_ctxs.erase(g_ctxs.begin() + (std::ptrdiff_t)i); break; }
     }
-    if (c->stage) hipHostFree(c->stage);
-    if (c->ev0) hipEventDestroy(c->ev0);
-    if (c->ev1) hipEventDestroy(c->ev1);
-    if (c->ev2) hipEventDestroy(c->ev2);
-    if (c->stream) hipStreamDestroy(c->stream);
-    delete c;
+    ctx_release(c);
     return MALCS_OK;
 }
 
@@ -343,7 +355,7 @@ int malcs_edit_distance_time_kernel(malcs_batch *b, int iters, float *ms_total)
     MALCS_HIP(hipSetDevice(c->device));
     MALCS_HIP(hipEventRecord(c->ev0, c->stream));
     for (int i = 0; i < iters; i++) {
-        int rc = malcs_diag_launch(b, false);      // appends beyond a list's capacity are dropped by the kernel
+        int rc = malcs_diag_launch(b, true);       // every launch starts from zeroed retry counters, as in a real step
         if (rc) return rc;
     }
     MALCS_HIP(hipEventRecord(c->ev1, c->stream));
