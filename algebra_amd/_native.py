@@ -50,6 +50,7 @@ def _load():
         "malcs_edit_distance_time_kernel": (c.c_int, [vp, c.c_int, P(c.c_float)]),
         "malcs_batch_plan_info": (c.c_int, [vp, P(c.c_uint64)]),
         "malcs_edit_distance_batch": (c.c_int, [vp, vp, u64, vp, vp, vp, vp, u64, c.c_int, vp]),
+        "malcs_edit_distance_noalloc": (c.c_int, [vp, vp, vp, u64, vp, vp, vp, vp, u64, c.c_int, vp]),
         "malcs_lcs_graph_batch": (c.c_int, [vp, vp, vp, P(vp)]),
         "malcs_lcs_nodes_batch": (c.c_int, [vp, vp, vp, P(vp)]),
         "malcs_graphs_destroy": (c.c_int, [vp]),

@@ -121,7 +121,7 @@ static int ctx_setup(malcs_ctx *c)
     MALCS_HIP(hipEventCreate(&c->ev2));
     if (hipHostMalloc((void **)&c->stage, STAGE_BYTES, hipHostMallocDefault) == hipSuccess) c->stage_cap = STAGE_BYTES;
     else { c->stage = nullptr; (void)hipGetLastError(); }        // no staging: copies go straight from pageable memory
-    return MALCS_OK;
+    return malcs_noalloc_setup(c);
 }
 
 extern "C" {

@@ -96,4 +96,21 @@ __device__ __forceinline__ uint64_t zero_mask()
     return z;
 }
 
+// One block of 32 symbols -> NP plane dwords: bit j of out[p] = bit p of the code of symbol j; symbols past
+// `cnt` pack as code 0.  Returns the OR of all codes read (callers that validate the alphabet look at it).
+template <int NP>
+__device__ __forceinline__ uint32_t pack_block(const uint8_t *__restrict__ src, uint32_t cnt, uint32_t (&out)[NP])
+{
+#pragma unroll
+    for (int p = 0; p < NP; p++) out[p] = 0;
+    uint32_t seen = 0;
+    for (uint32_t j = 0; j < cnt; j++) {
+        const uint32_t c = src[j];
+        seen |= c;
+#pragma unroll
+        for (int p = 0; p < NP; p++) out[p] |= ((c >> p) & 1u) << j;
+    }
+    return seen;
+}
+
 }  // namespace malcs_dev

@@ -361,6 +361,28 @@ uint32_t pow2ceil(uint32_t x) { uint32_t p = 1; while (p < x) p <<= 1; return p;
 
 }  // namespace
 
+// One full-matrix launch over a work list whose length sits in device memory (*d_count, read by the kernel):
+// pairs list[first .. first + min(*d_count, cap)) in class (W words per lane, L lanes per pair), `waves` waves.
+int malcs_dist_launch_list(hipStream_t st, int n_planes, int W, int L, const uint32_t *d_planes,
+                           const uint32_t *d_a_off, const uint32_t *d_a_len, const uint32_t *d_b_off, const uint32_t *d_b_len,
+                           const uint32_t *d_list, uint32_t first, const uint32_t *d_count, uint32_t cap, uint32_t waves,
+                           int32_t *d_dist)
+{
+    int logL = 0;
+    while ((1 << logL) < L) logL++;
+    list_kernel_t fn = nullptr;
+    switch (n_planes) {
+    case 2: fn = pick_list_kernel<2>(W, L > 1); break;
+    case 3: fn = pick_list_kernel<3>(W, L > 1); break;
+    case 4: fn = pick_list_kernel<4>(W, L > 1); break;
+    }
+    if (!fn) { malcs_set_error("no distance kernel for W=%d planes=%d", W, n_planes); return MALCS_ERR_INTERNAL; }
+    hipLaunchKernelGGL(fn, dim3((std::max(waves, 1u) + 3u) / 4u), dim3(256), 0, st, d_planes, d_a_off, d_a_len,
+                       d_b_off, d_b_len, d_list, first, d_count, cap, logL, d_dist);
+    MALCS_HIP(hipGetLastError());
+    return MALCS_OK;
+}
+
 // Group the pairs of a batch into launch classes (W words per lane, L lanes per pair).
 int malcs_dist_plan(malcs_batch *b)
 {
@@ -464,21 +486,12 @@ int malcs_dist_launch_resident(malcs_batch *b)
         for (size_t c = 0; c < b->diag.retry.size(); c++) {
             const diag_retry &r = b->diag.retry[c];
             if (!r.cap) continue;
-            int logL = 0;
-            while ((1 << logL) < r.L) logL++;
-            list_kernel_t fn = nullptr;
-            switch (b->n_planes) {
-            case 2: fn = pick_list_kernel<2>(r.W, r.L > 1); break;
-            case 3: fn = pick_list_kernel<3>(r.W, r.L > 1); break;
-            case 4: fn = pick_list_kernel<4>(r.W, r.L > 1); break;
-            }
-            if (!fn) { malcs_set_error("no distance kernel for W=%d planes=%d", r.W, b->n_planes); return MALCS_ERR_INTERNAL; }
             const uint32_t ppw = 64u / (uint32_t)r.L;
-            const uint32_t waves = std::min<uint32_t>((r.cap + ppw - 1u) / ppw, 1024u);
-            hipLaunchKernelGGL(fn, dim3((waves + 3u) / 4u), dim3(256), 0, b->ctx->stream, b->d_planes, b->d_a_off, b->d_a_len,
-                               b->d_b_off, b->d_b_len, b->diag.d_retry_list, r.first,
-                               b->diag.d_retry_count + b->diag.parity * std::max<size_t>(b->diag.retry.size(), 1) + c, r.cap, logL, b->d_dist);
-            MALCS_HIP(hipGetLastError());
+            const int rc2 = malcs_dist_launch_list(b->ctx->stream, b->n_planes, r.W, r.L, b->d_planes, b->d_a_off, b->d_a_len,
+                                                   b->d_b_off, b->d_b_len, b->diag.d_retry_list, r.first,
+                                                   b->diag.d_retry_count + b->diag.parity * std::max<size_t>(b->diag.retry.size(), 1) + c,
+                                                   r.cap, std::min<uint32_t>((r.cap + ppw - 1u) / ppw, 1024u), b->d_dist);
+            if (rc2) return rc2;
         }
     }
     for (const dist_bucket &k : b->dist_buckets) {

@@ -59,6 +59,7 @@ struct malcs_ctx {
     char *stage = nullptr;
     size_t stage_cap = 0, stage_used = 0;
     std::vector<staged_copy> staged;
+    uint32_t *noalloc_scratch = nullptr;   // this device's copy of the file-scope scratch array of malcs_noalloc.hip
 };
 
 // Copies on a context's stream and the wait for them.  Small copies are staged through the context's pinned buffer:
@@ -117,6 +118,9 @@ struct malcs_batch {
     uint32_t max_len = 0;
 };
 
+// malcs_noalloc.hip
+int malcs_noalloc_setup(malcs_ctx *c);
+
 // malcs_pack.hip
 int malcs_pack_launch(malcs_ctx *ctx, const uint8_t *d_syms, const uint64_t *d_seq_byte_off,
                       const uint32_t *d_seq_len, const uint32_t *d_seq_blk_off, uint32_t n_seqs,
@@ -135,6 +139,10 @@ int malcs_dist_plan(malcs_batch *b);
 int malcs_dist_launch(malcs_batch *b);
 int malcs_dist_launch_resident(malcs_batch *b);
 int malcs_dist_band(malcs_batch *b, const std::vector<uint32_t> &pairs, int32_t *host_out);
+int malcs_dist_launch_list(hipStream_t st, int n_planes, int W, int L, const uint32_t *d_planes,
+                           const uint32_t *d_a_off, const uint32_t *d_a_len, const uint32_t *d_b_off, const uint32_t *d_b_len,
+                           const uint32_t *d_list, uint32_t first, const uint32_t *d_count, uint32_t cap, uint32_t waves,
+                           int32_t *d_dist);
 
 // malcs_sweep.hip
 int malcs_sweep_distances(malcs_batch *b, const std::vector<uint32_t> &pairs, int32_t cap, std::vector<int32_t> &out);

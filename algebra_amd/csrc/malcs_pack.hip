@@ -8,6 +8,7 @@
 // loads otherwise), n_planes dwords out.  Threads of a wave touch consecutive blocks, so both
 // sides are coalesced.
 #include "malcs_internal.hpp"
+#include "malcs_device.hpp"
 
 template <int NP>
 __global__ void __launch_bounds__(256)
@@ -29,13 +30,7 @@ k_pack_planes(const uint8_t *__restrict__ syms, const uint64_t *__restrict__ seq
     uint32_t cnt = len - k * 32u;
     if (cnt > 32u) cnt = 32u;
     uint32_t out[NP];
-#pragma unroll
-    for (int p = 0; p < NP; p++) out[p] = 0;
-    for (uint32_t j = 0; j < cnt; j++) {
-        uint32_t c = src[j];
-#pragma unroll
-        for (int p = 0; p < NP; p++) out[p] |= ((c >> p) & 1u) << j;
-    }
+    malcs_dev::pack_block<NP>(src, cnt, out);
 #pragma unroll
     for (int p = 0; p < NP; p++) planes[(uint64_t)blk * NP + p] = out[p];
 }

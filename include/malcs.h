@@ -106,6 +106,31 @@ int malcs_edit_distance_batch(malcs_ctx *ctx, const uint8_t *syms, uint64_t n_sy
                               const uint64_t *b_off, const uint32_t *b_len,
                               uint64_t n_pairs, int n_symbols, int32_t *dist);
 
+/* ---- the entry point that allocates nothing ---------------------------------------------------
+ * NO COUNTERPART IN THE REFERENCE.  For callers that cannot allocate device memory: code under HIP graph
+ * capture, tight serving loops, harnesses that forbid hipMalloc.  Same result as malcs_edit_distance_batch
+ * (edit_distance(a, b), algebra/lcs/edit_distance.py:21-53), but inputs and output are DEVICE addresses on the
+ * context's device and the call performs no hipMalloc / hipFree / host-device copy / synchronisation: it enqueues
+ * its kernels on `stream` (a hipStream_t; NULL = the context's stream) and returns.  Read d_dist after that
+ * stream has been synchronised (malcs_ctx_sync for the context's stream).
+ *
+ * Everything between input and output (bit planes, per-pair tables, work lists, counters) lives in one
+ * file-scope device array of the library (14 MB per GPU, held until the process ends).  Limits, checked here:
+ * n_pairs <= MALCS_NOALLOC_MAX_PAIRS, n_syms <= MALCS_NOALLOC_MAX_SYMS, 1 <= n_symbols <= 16 (else
+ * MALCS_ERR_TOO_LONG / MALCS_ERR_ARG, nothing is enqueued).  Checked on the device, per pair (d_dist[i] = -1,
+ * the other pairs are unaffected): a sequence outside [0, n_syms), a shorter sequence of more than
+ * MALCS_NOALLOC_MAX_LEN symbols, or packed sequences beyond the arena (the sum over all 2 n_pairs sequences of
+ * ceil(len / 32) must not exceed MALCS_NOALLOC_PLANE_DWORDS / planes, planes = 2, 3, 4 for <= 4, 8, 16 symbols).
+ * All calls on one GPU share that array: calls that overlap on one GPU (two streams, two threads) race. */
+#define MALCS_NOALLOC_MAX_PAIRS 65536u
+#define MALCS_NOALLOC_MAX_LEN 16384u
+#define MALCS_NOALLOC_MAX_SYMS (32ull << 20)
+#define MALCS_NOALLOC_PLANE_DWORDS (2u << 20)
+int malcs_edit_distance_noalloc(malcs_ctx *ctx, void *stream, const uint8_t *d_syms, uint64_t n_syms,
+                                const uint64_t *d_a_off, const uint32_t *d_a_len,
+                                const uint64_t *d_b_off, const uint32_t *d_b_len,
+                                uint64_t n_pairs, int n_symbols, int32_t *d_dist);
+
 /* ---- kernel family 2: batched LCS graphs ----------------------------------------------------
  * Stands in for LCSgraph.__init__(reference, observed, shift, max_distance)
  * (algebra/lcs/lcs_graph.py:59-61) = _lcs_nodes (:238-348) + _build_graph (:351-453), for every

@@ -1,0 +1,87 @@
+"""The entry point that allocates nothing (malcs_edit_distance_noalloc, include/malcs.h) against the existing
+malcs_edit_distance_batch, through the C-ABI: two calls in a row on one GPU, the second with a smaller input
+(the file-scope scratch array keeps the first call's contents), bit-exact.
+
+torch only supplies the device buffers a caller of this entry point would already own."""
+
+import ctypes
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+def _pairs(rs, lengths, n_symbols, indel=0.02):
+    seqs = []
+    for m in lengths:
+        a = rs.randint(0, n_symbols, m).astype(np.uint8)
+        keep = rs.random_sample(m) > indel
+        b = np.concatenate([a[keep], rs.randint(0, n_symbols, rs.randint(0, 4)).astype(np.uint8)])
+        seqs += [a, b] if rs.randint(2) else [b, a]
+    lens = np.array([len(x) for x in seqs], np.uint32)
+    off = np.concatenate([[0], np.cumsum(lens[:-1], dtype=np.uint64)]).astype(np.uint64)
+    syms = np.concatenate(seqs + [np.zeros(1, np.uint8)])
+    return syms, off[0::2].copy(), lens[0::2].copy(), off[1::2].copy(), lens[1::2].copy()
+
+
+def _existing(native, ctx, data, n_symbols):
+    syms, a_off, a_len, b_off, b_len = data
+    out = np.empty(len(a_off), np.int32)
+    native.check(native.lib.malcs_edit_distance_batch(ctx.handle, native.ptr(syms), syms.size, native.ptr(a_off), native.ptr(a_len),
+                                                      native.ptr(b_off), native.ptr(b_len), len(a_off), n_symbols, native.ptr(out)))
+    return out
+
+
+def _noalloc(native, ctx, torch, data, n_symbols):
+    dev = torch.device("cuda", ctx.device)
+    t = [torch.from_numpy(x.view(np.int64) if x.dtype == np.uint64 else (x.view(np.int32) if x.dtype == np.uint32 else x)).to(dev)
+         for x in data]
+    out = torch.full((len(data[1]),), -7, dtype=torch.int32, device=dev)
+    torch.cuda.synchronize(dev)
+    p = [ctypes.c_void_p(x.data_ptr()) for x in t]
+    rc = native.lib.malcs_edit_distance_noalloc(ctx.handle, None, p[0], data[0].size, p[1], p[2], p[3], p[4], len(data[1]), n_symbols,
+                                                ctypes.c_void_p(out.data_ptr()))
+    native.check(rc)
+    ctx.sync()
+    return out.cpu().numpy()
+
+
+def test_noalloc_matches_existing_entry_two_calls():
+    import torch
+    from algebra_amd import _native as native
+    ctx = native.default_context()
+    rs = np.random.RandomState(77)
+    # first call: every launch class (1 ... 16 384 symbols on the shorter side), DNA
+    lengths = [0, 1, 31, 64, 65, 128, 129, 255, 256, 257, 300, 511, 513, 1000, 1024, 1025, 2047, 2049, 4096, 4097, 8191, 8193, 16384]
+    lengths += list(rs.randint(0, 3000, 4000))
+    big = _pairs(rs, lengths, 4)
+    want = _existing(native, ctx, big, 4)
+    got = _noalloc(native, ctx, torch, big, 4)
+    assert np.array_equal(got, want)
+    # second call, smaller, other alphabet (three planes): the scratch array still holds the first call's lists
+    small = _pairs(rs, list(rs.randint(0, 700, 300)) + [5000, 0, 33], 7, indel=0.1)
+    want = _existing(native, ctx, small, 8)
+    got = _noalloc(native, ctx, torch, small, 8)
+    assert np.array_equal(got, want)
+    # and the first again: same answers as before
+    assert np.array_equal(_noalloc(native, ctx, torch, big, 4), _existing(native, ctx, big, 4))
+
+
+def test_noalloc_limits():
+    import torch
+    from algebra_amd import _native as native
+    ctx = native.default_context()
+    rs = np.random.RandomState(78)
+    # beyond the maximum number of pairs: rejected with a clear error, nothing enqueued
+    rc = native.lib.malcs_edit_distance_noalloc(ctx.handle, None, None, 0, None, None, None, None, 65537, 4, None)
+    assert rc == -4 and b"at most 65536 pairs" in native.lib.malcs_last_error()
+    rc = native.lib.malcs_edit_distance_noalloc(ctx.handle, None, None, 0, None, None, None, None, 1, 17, None)
+    assert rc == -1
+    # per pair on the device: a shorter side beyond 16 384 symbols, a sequence outside the buffer -> -1, the others exact
+    data = list(_pairs(rs, [100, 17000, 200], 4))
+    want = _existing(native, ctx, tuple(data), 4)
+    data[3] = data[3].copy()
+    data[3][2] = np.uint64(data[0].size)                       # pair 2: b starts at the end of the buffer and has symbols
+    got = _noalloc(native, ctx, torch, tuple(data), 4)
+    assert got[0] == want[0] and got[1] == -1 and got[2] == -1
