@@ -96,9 +96,56 @@ hipError_t malcs_sync(hipStream_t st)
     return c ? drain(c) : hipStreamSynchronize(st);
 }
 
+// ---- pooled device memory ---------------------------------------------------------------------------
+hipError_t malcs_pool_alloc(malcs_ctx *c, void **p, size_t bytes)
+{
+    if (!bytes) bytes = 256;
+    bytes = (bytes + 255u) & ~(size_t)255u;
+    size_t best = (size_t)-1;
+    for (size_t i = 0; i < c->pool.size(); i++) {                // smallest free block that is not wastefully large
+        const malcs_ctx::pool_block &k = c->pool[i];
+        if (!k.used && k.bytes >= bytes && k.bytes <= 2 * bytes + (1u << 20) && (best == (size_t)-1 || k.bytes < c->pool[best].bytes)) best = i;
+    }
+    if (best != (size_t)-1) { c->pool[best].used = true; *p = c->pool[best].p; return hipSuccess; }
+    hipError_t e = hipMalloc(p, bytes);
+    if (e != hipSuccess) {                                       // make room from what the pool holds and try once more
+        (void)hipGetLastError();
+        malcs_pool_trim(c);
+        e = hipMalloc(p, bytes);
+        if (e != hipSuccess) return e;
+    }
+    c->pool.push_back({*p, bytes, true});
+    c->pool_bytes += bytes;
+    return hipSuccess;
+}
+
+void malcs_pool_free(malcs_ctx *c, void *p)
+{
+    if (!p) return;
+    for (malcs_ctx::pool_block &k : c->pool) if (k.p == p) { k.used = false; break; }
+    // a context that has seen one huge batch does not sit on its memory for ever
+    size_t idle = 0;
+    for (const malcs_ctx::pool_block &k : c->pool) if (!k.used) idle += k.bytes;
+    if (idle > (8ull << 30) || c->pool.size() > 256) malcs_pool_trim(c);
+}
+
+void malcs_pool_trim(malcs_ctx *c)
+{
+    if (c->stream) (void)hipStreamSynchronize(c->stream);        // queued work may still read a released block
+    size_t kept = 0;
+    for (size_t i = 0; i < c->pool.size(); i++) {
+        if (c->pool[i].used) { c->pool[kept++] = c->pool[i]; continue; }
+        (void)hipFree(c->pool[i].p);
+        c->pool_bytes -= c->pool[i].bytes;
+    }
+    c->pool.resize(kept);
+}
+
 // everything a context owns, released in reverse order of creation (also on the error paths of malcs_ctx_create)
 static void ctx_release(malcs_ctx *c)
 {
+    malcs_pool_trim(c);
+    if (c->pack_stage) hipHostFree(c->pack_stage);
     if (c->stage) hipHostFree(c->stage);
     if (c->ev0) hipEventDestroy(c->ev0);
     if (c->ev1) hipEventDestroy(c->ev1);

@@ -47,34 +47,139 @@ using namespace malcs_dev;
 constexpr int META_ROWS = 4;          // pid, m, n, kmax | retry class << 16
 constexpr int MALCS_DIAG_HALF_T = 48; // two limbs moving 16 rows per 16 columns: 64 - 16 diagonals
 
-// ---- plan-time layout --------------------------------------------------------------------------
-// grid (rows of the longest tile, tiles), block 64: thread = (tile, row r, lane)
+// ---- the plan, on the device ---------------------------------------------------------------------
+// What a batch needs before its window class can run: the common ends of every pair (they do not change the distance,
+// so they stay out of the window), the pairs sorted by what is left, cut into tiles of 64 lanes, the tiles cut into the
+// pieces that run as workgroups, and the rows of every piece.  Everything that touches pairs runs here, on the packed
+// planes; the host only sees a histogram of lengths (one small copy, the plan's only synchronisation) and works out
+// tiles and pieces from it.
+//
+// items: nine arrays of `count` dwords, one entry per pair of the class (in the order of `pairs`)
+enum { IT_PO, IT_TO, IT_M, IT_N, IT_Q, IT_MT, IT_NT, IT_DELTA, IT_ITERS, ITEM_FIELDS };
+
+// One lane per pair: common prefix / suffix from the planes (XOR of whole words, first / last differing bit), what is left
+// of the pair after the cut, and the histogram of block counts the tiles are formed from (two groups: length
+// differences the two-limb mode holds, and the others).
 template <int NP>
-__global__ void __launch_bounds__(64)
-k_diag_layout(const uint32_t *__restrict__ planes,
-              const uint32_t *__restrict__ tile_po, const uint32_t *__restrict__ tile_to,
-              const uint32_t *__restrict__ tile_m, const uint32_t *__restrict__ tile_n, const uint32_t *__restrict__ tile_q,
-              const uint32_t *__restrict__ tile_mt, const uint32_t *__restrict__ tile_nt,
-              const uint32_t *__restrict__ tile_pid, const uint32_t *__restrict__ tile_kc,
-              const uint32_t *__restrict__ tile_off, const uint32_t *__restrict__ tile_iters,
-              int nlw, uint32_t *__restrict__ rows)
+__global__ void __launch_bounds__(256)
+k_plan_ends(const uint32_t *__restrict__ planes, const uint32_t *__restrict__ a_off, const uint32_t *__restrict__ a_len,
+            const uint32_t *__restrict__ b_off, const uint32_t *__restrict__ b_len, const uint32_t *__restrict__ pairs,
+            uint32_t count, uint32_t min_rows, int trim, uint32_t hist_stride, uint32_t *__restrict__ item, uint32_t *__restrict__ hist)
 {
-    const uint32_t tile = blockIdx.y, r = blockIdx.x, lane = threadIdx.x;
-    const uint32_t iters = tile_iters[tile] & 0x7fffffffu;         // bit 31: the tile runs in two-limb mode (same rows)
-    if (r >= (uint32_t)(nlw - 1) + iters) return;
-    const uint32_t slot = tile * 64u + lane;
-    const uint32_t pid = tile_pid[slot];
-    const uint32_t kc = tile_kc[slot];
-    // pattern (the shorter sequence) and text of the slot, common ends already cut off by the plan: both start q symbols
-    // (0 ... 31) into the block at po / to and have m / n symbols from there
-    const uint32_t m = tile_m[slot], n = tile_n[slot], po = tile_po[slot], to = tile_to[slot], q = tile_q[slot];
-    // symbols really stored from po / to on; m and n may reach beyond them: the plan lengthens both sequences by the same
-    // number of symbols to make the text whole blocks, and what lies beyond the end reads as symbol 0 on both sides --
-    // a common suffix, which does not change the distance
-    const int mt = (int)tile_mt[slot], nt = (int)tile_nt[slot];
-    uint32_t *out = rows + (size_t)tile_off[tile] * 64u + lane;
-    if (r == 0) { out[0] = pid; out[64] = m; out[128] = n; out[192] = kc; }
-    const int kmax = (int)(kc & 0xffffu);
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= count) return;
+    const uint32_t pid = pairs[i];
+    const uint32_t la = a_len[pid], lb = b_len[pid];
+    const bool a_short = la <= lb;
+    uint32_t m = a_short ? la : lb, n = a_short ? lb : la;
+    uint32_t po = a_short ? a_off[pid] : b_off[pid], to = a_short ? b_off[pid] : a_off[pid];
+    uint32_t q = 0, mt = m, nt = n;
+    const uint32_t delta = n - m;
+    if (trim && m > min_rows) {
+        // as LCSgraph.from_sequence cuts them off with trim() (lcs_graph.py:231-235), but never below the rows the
+        // window class needs
+        const uint32_t room = m - min_rows;
+        uint32_t pre = room;
+        for (uint32_t w = 0; 32u * w < room; w++) {
+            uint32_t x = 0;
+#pragma unroll
+            for (int p = 0; p < NP; p++) x |= planes[po + w * NP + p] ^ planes[to + w * NP + p];
+            if (x) { pre = min(room, 32u * w + (uint32_t)__builtin_ctz(x)); break; }
+        }
+        // 32 symbols ending at position e (e >= 32 here: at least min_rows symbols stay in front of the suffix)
+        auto chunk = [&](uint32_t base, uint32_t e, int p) -> uint32_t {
+            const uint32_t at = e - 32u, wd = at >> 5, sh = at & 31u;
+            const uint32_t lo = planes[base + wd * NP + p];
+            return sh ? ((lo >> sh) | (planes[base + (wd + 1u) * NP + p] << (32u - sh))) : lo;
+        };
+        const uint32_t rem = room - pre;
+        uint32_t suf = 0, ea = m, eb = n;
+        while (suf < rem) {
+            uint32_t x = 0;
+#pragma unroll
+            for (int p = 0; p < NP; p++) x |= chunk(po, ea, p) ^ chunk(to, eb, p);
+            const uint32_t c = x ? (uint32_t)__builtin_clz(x) : 32u;
+            suf += min(c, rem - suf);
+            if (c < 32u) break;
+            ea -= 32u; eb -= 32u;
+        }
+        po += (pre >> 5) * NP; to += (pre >> 5) * NP; q = pre & 31u;
+        m -= pre + suf; n -= pre + suf;
+        mt = q + m + suf; nt = q + n + suf;
+    }
+    // a text of whole blocks has no masked last block: both sequences grow by the same symbols at the end (what was cut
+    // off there first, symbol 0 beyond the end: see k_diag_layout)
+    const uint32_t ragged = (32u - (n & 31u)) & 31u;
+    m += ragged; n += ragged;
+    const uint32_t iters = n >> 5;
+    item[IT_PO * count + i] = po; item[IT_TO * count + i] = to; item[IT_M * count + i] = m; item[IT_N * count + i] = n;
+    item[IT_Q * count + i] = q; item[IT_MT * count + i] = mt; item[IT_NT * count + i] = nt;
+    item[IT_DELTA * count + i] = delta; item[IT_ITERS * count + i] = iters;
+    atomicAdd(&hist[(delta > (uint32_t)MALCS_DIAG_HALF_T ? hist_stride : 0u) + iters], 1u);
+}
+
+// Counting sort by (group, blocks): `cursor` starts as the host's exclusive scan of the histogram (in the order the
+// tiles are formed in); slot s of the sorted order gets the index of its item.  Pairs of equal key may land in any
+// order: they are interchangeable (same block count, same mode).
+__global__ void __launch_bounds__(256)
+k_plan_scatter(const uint32_t *__restrict__ item, uint32_t count, uint32_t hist_stride, uint32_t *__restrict__ cursor,
+               uint32_t *__restrict__ slot_item)
+{
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= count) return;
+    const uint32_t key = (item[IT_DELTA * count + i] > (uint32_t)MALCS_DIAG_HALF_T ? hist_stride : 0u) + item[IT_ITERS * count + i];
+    slot_item[atomicAdd(&cursor[key], 1u)] = i;
+}
+
+// piece_info: blocks of the piece | PIECE_* flags
+constexpr uint32_t PIECE_HALF = 1u << 31;     // two-limb mode (T = 48)
+constexpr uint32_t PIECE_JOINED = 1u << 30;   // one of the two pieces of a tile that was cut: the results meet in the join buffer
+constexpr uint32_t PIECE_BACK = 1u << 29;     // ... the one that runs the reversed sequences from the far end
+constexpr uint32_t PIECE_BLOCKS = (1u << 29) - 1u;
+
+// The rows of every piece.  grid = pieces, 256 threads: lane = slot of the tile, the four waves take the rows of the
+// piece in turn.  A piece that runs backwards gets the rows of the reversed pair: pattern row r' is row m - 1 - r',
+// text column j' is column n - 1 - j' (n is whole blocks), i.e. the same words bit-reversed and in reverse order.
+template <int NP>
+__global__ void __launch_bounds__(256)
+k_diag_layout(const uint32_t *__restrict__ planes, const uint32_t *__restrict__ item, uint32_t count,
+              const uint32_t *__restrict__ pairs, const uint8_t *__restrict__ retry_class,
+              const uint32_t *__restrict__ slot_item, const uint32_t *__restrict__ tile_iters,
+              const uint32_t *__restrict__ piece_off, const uint32_t *__restrict__ piece_info,
+              const uint32_t *__restrict__ piece_tile, int nlw, int T, uint32_t *__restrict__ rows)
+{
+    const uint32_t piece = blockIdx.x, lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
+    const uint32_t info = piece_info[piece], tile = piece_tile[piece];
+    const uint32_t nb = info & PIECE_BLOCKS;
+    const bool back = info & PIECE_BACK;
+    const uint32_t n_rows = (uint32_t)(nlw - 1) + nb;
+    const uint32_t idx = slot_item[tile * 64u + lane];
+    uint32_t *out = rows + (size_t)piece_off[piece] * 64u + lane;
+    if (idx == 0xffffffffu) {                                  // an empty slot of the last tile
+        if (wave == 0) { out[0] = 0xffffffffu; out[64] = 0u; out[128] = 0u; out[192] = 0u; }
+        out += META_ROWS * 64;
+        for (uint32_t r = wave; r < n_rows; r += 4) {
+            const uint32_t k = r < (uint32_t)(nlw - 1) ? NP : 2 * NP;
+            uint32_t *o = out + (r < (uint32_t)(nlw - 1) ? (size_t)r * NP : (size_t)(nlw - 1) * NP + (size_t)(r - (nlw - 1)) * 2u * NP) * 64u;
+            for (uint32_t j = 0; j < k; j++) o[j * 64u] = 0u;
+        }
+        return;
+    }
+    // pattern (the shorter sequence) and text of the slot, common ends already cut off by k_plan_ends: both start q
+    // symbols (0 ... 31) into the block at po / to and have m / n symbols from there.  Symbols really stored: mt / nt;
+    // m and n reach beyond them: both sequences were lengthened by the same number of symbols to make the text whole
+    // blocks and as long as the longest of its tile, and what lies beyond the end reads as symbol 0 on both sides -- a
+    // common suffix, which does not change the distance.
+    const uint32_t it_tile = tile_iters[tile] & 0x7fffffffu;
+    const bool half = tile_iters[tile] >> 31;
+    const uint32_t grow = 32u * (it_tile - item[IT_ITERS * count + idx]);
+    const uint32_t m = item[IT_M * count + idx] + grow, n = item[IT_N * count + idx] + grow;
+    const uint32_t po = item[IT_PO * count + idx], to = item[IT_TO * count + idx], q = item[IT_Q * count + idx];
+    const int mt = (int)item[IT_MT * count + idx], nt = (int)item[IT_NT * count + idx];
+    const int delta = (int)item[IT_DELTA * count + idx];
+    const int Tm = half ? MALCS_DIAG_HALF_T : T;
+    const int kmax = delta + (Tm - delta) / 2;
+    if (wave == 0) { out[0] = pairs[idx]; out[64] = m; out[128] = n; out[192] = (uint32_t)kmax | ((uint32_t)retry_class[idx] << 16); }
     out += META_ROWS * 64;
     auto stored = [&](uint32_t base, int have, int wd, int p) -> uint32_t {    // word wd of a stored sequence, zero beyond its end
         const int valid = have - 32 * wd;
@@ -82,30 +187,41 @@ k_diag_layout(const uint32_t *__restrict__ planes,
         const uint32_t w = planes[base + (uint32_t)wd * NP + p];
         return valid >= 32 ? w : (w & ((1u << valid) - 1u));
     };
-    // 32 rows of the pattern from row rs (negative: above the matrix, those bits never matter) / 32 columns of the
-    // text from column 32 blk; both as cut, i.e. q symbols into the stored sequence
-    auto limb = [&](int rs, int p) -> uint32_t {
+    // 32 rows of the pattern from row rs (negative: above the matrix, those bits never matter) / the 32 columns of
+    // block blk of the text; both as cut, i.e. q symbols into the stored sequence
+    auto limb_fwd = [&](int rs, int p) -> uint32_t {
         const int at = rs + (int)q, wd = at >> 5;                        // arithmetic shift = floor
         const uint32_t sh = (uint32_t)at & 31u;
         const uint32_t lo = stored(po, mt, wd, p);
         return sh ? ((lo >> sh) | (stored(po, mt, wd + 1, p) << (32u - sh))) : lo;
     };
-    auto text = [&](int blk, int p) -> uint32_t {
+    auto text_fwd = [&](int blk, int p) -> uint32_t {
         const uint32_t lo = stored(to, nt, blk, p);
         return q ? ((lo >> q) | (stored(to, nt, blk + 1, p) << (32u - q))) : lo;
     };
-    if (r < (uint32_t)(nlw - 1)) {
+    auto limb = [&](int rs, int p) -> uint32_t { return back ? __brev(limb_fwd((int)m - rs - 32, p)) : limb_fwd(rs, p); };
+    auto text = [&](int blk, int p) -> uint32_t { return back ? __brev(text_fwd((int)(n >> 5) - 1 - blk, p)) : text_fwd(blk, p); };
+    for (uint32_t r = wave; r < n_rows; r += 4) {
+        if (r < (uint32_t)(nlw - 1)) {
 #pragma unroll
-        for (int p = 0; p < NP; p++) out[(r * NP + p) * 64u] = limb(32 * (int)r - kmax, p);
-        return;
-    }
-    const int it = (int)r - (nlw - 1);
-    out += (size_t)(nlw - 1) * NP * 64u + (size_t)it * 2u * NP * 64u;
+            for (int p = 0; p < NP; p++) out[(r * NP + p) * 64u] = limb(32 * (int)r - kmax, p);
+        } else {
+            const int it = (int)r - (nlw - 1);
+            uint32_t *o = out + (size_t)(nlw - 1) * NP * 64u + (size_t)it * 2u * NP * 64u;
 #pragma unroll
-    for (int p = 0; p < NP; p++) {
-        out[p * 64u] = limb(32 * (it + nlw - 1) - kmax, p);
-        out[(NP + p) * 64u] = text(it, p);
+            for (int p = 0; p < NP; p++) {
+                o[p * 64u] = limb(32 * (it + nlw - 1) - kmax, p);
+                o[(NP + p) * 64u] = text(it, p);
+            }
+        }
     }
+}
+
+__global__ void __launch_bounds__(256)
+k_plan_gather(const int32_t *__restrict__ dist, const uint32_t *__restrict__ list, uint32_t n, int32_t *__restrict__ out)
+{
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) out[i] = dist[list[i]];
 }
 
 // ---- one block of 32 columns, skewed inside the lane ---------------------------------------------
@@ -466,23 +582,32 @@ __device__ __forceinline__ void diag_block(uint32_t (&V)[NLW], const uint32_t (&
 }
 
 // ---- the window kernel -------------------------------------------------------------------------
+// One workgroup (one wave) per piece.  A piece is a whole tile, or one of the two parts of a tile in two-limb mode that
+// the plan cut at a block boundary: the front part runs the pair's first columns forwards, the back part runs the
+// reversed pair from its far end, and whichever finishes second joins them.  Joining at column J: the front part knows
+// Lf(i) = LLCS(pattern[0, i), text[0, J)) for the 64 rows i of its window, the back part Lb(i) = LLCS(pattern[i, m),
+// text[J, n)) for the 64 rows of its own; both windows hold the band of diagonals an alignment of cost <= T can visit,
+// so LLCS' = max over the rows i in both windows of Lf(i) + Lb(i) is exact under the same condition as a whole tile
+// (D' <= T).  In window coordinates x = i - (first row of the front window) the two windows overlap in x = 0 ... S,
+// S = 2 kmax - delta (47 or 48), Lf = banked zeros + zero bits of the front V below x, Lb likewise below S - x.
 template <int NLW, int NP, bool FUSED = true>
 __global__ void __launch_bounds__(64)
-k_llcs_diag(const uint32_t *__restrict__ rows, const uint32_t *__restrict__ tile_off,
-            const uint32_t *__restrict__ tile_iters, int32_t *__restrict__ dist,
+k_llcs_diag(const uint32_t *__restrict__ rows, const uint32_t *__restrict__ piece_off,
+            const uint32_t *__restrict__ piece_info, const uint32_t *__restrict__ piece_join, int32_t *__restrict__ dist,
             uint32_t *__restrict__ retry_list, const uint32_t *__restrict__ retry_first,
             const uint32_t *__restrict__ retry_cap, uint32_t *__restrict__ retry_count,
-            uint32_t *__restrict__ retry_count_next, uint32_t n_classes)
+            uint32_t *__restrict__ retry_count_next, uint32_t n_classes,
+            uint32_t *__restrict__ join_buf, uint32_t *__restrict__ join_flag)
 {
     constexpr int T = 32 * NLW - 32;
     // the counters of the NEXT launch start at zero: nothing in flight reads or writes that set now
     if (blockIdx.x == 0 && threadIdx.x < n_classes) retry_count_next[threadIdx.x] = 0u;
     const unsigned lane = threadIdx.x;
     const uint32_t tile = blockIdx.x;
-    const uint32_t *p = rows + (size_t)__builtin_amdgcn_readfirstlane(tile_off[tile]) * 64u + lane;
-    const uint32_t mode_iters = __builtin_amdgcn_readfirstlane(tile_iters[tile]);
-    const int iters = (int)(mode_iters & 0x7fffffffu);
-    const bool halves = NLW == 3 && NP == 2 && FUSED && (mode_iters >> 31);     // two limbs, half-limb steps (T = 48)
+    const uint32_t *p = rows + (size_t)__builtin_amdgcn_readfirstlane(piece_off[tile]) * 64u + lane;
+    const uint32_t info = __builtin_amdgcn_readfirstlane(piece_info[tile]);
+    const int iters = (int)(info & PIECE_BLOCKS);
+    const bool halves = NLW == 3 && NP == 2 && FUSED && (info & PIECE_HALF);     // two limbs, half-limb steps (T = 48)
     const uint32_t pid = p[0], m = p[64], n = p[128], kc = p[192];
     const int kmax = (int)(kc & 0xffffu);          // block `it` = columns [32 it, 32 it + 32), its limb k = rows from 32 (it + k) - kmax
     p += META_ROWS * 64;
@@ -517,61 +642,110 @@ k_llcs_diag(const uint32_t *__restrict__ rows, const uint32_t *__restrict__ tile
         plain_hi = (int)min(n >> 5, (m + (uint32_t)kmax) >> 5);
     }
 
+    int32_t d = 0;
+    bool have_d = false;
     if constexpr (NLW == 3 && NP == 2 && FUSED) {
         if (halves) {                                  // every block of every lane is plain (the plan saw to that)
             uint32_t ones = 0;
             diag_halves_dna(V, P, ones, p, nxt, iters);
-            banked = 32u * (uint32_t)iters - ones;
-            above = kmax;                              // rows above the matrix were banked as zeros
-        }
-    }
-    for (int it = halves ? iters : 0; it < iters;) {
-        if constexpr (NLW == 3 && NP == 2 && FUSED) {
-            auto plain3 = [&](int i) { return i + 3 <= iters && __builtin_amdgcn_ballot_w64(i + 3 > plain_hi) == 0; };
-            if (plain3(it)) {
-                if (it == 0) above = kmax;                 // kmax <= 64: rows [-kmax, 0) lie in the first three leaving limbs
-                diag_triples_dna3(V, P, banked, p, nxt, it, plain3);
-                continue;
+            if (info & PIECE_JOINED) {
+                // the window now holds rows [32 iters - kmax, + 64) (inside the matrix: the plan leaves two blocks on
+                // either side of a cut); `ones` = one bits of the rows that left
+                const uint32_t jt = __builtin_amdgcn_readfirstlane(piece_join[tile]);
+                const uint32_t back = (info & PIECE_BACK) ? 1u : 0u;
+                uint32_t *mine = join_buf + ((size_t)jt * 2u + back) * 192u + lane;
+                const uint32_t *theirs = join_buf + ((size_t)jt * 2u + (back ^ 1u)) * 192u + lane;
+                __hip_atomic_store(mine, V[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                __hip_atomic_store(mine + 64, V[1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                __hip_atomic_store(mine + 128, ones, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                // The three stores and the loads below are agent-scope atomics (write-through / coherent across the
+                // XCDs' L2s by themselves), so no cache write-back or invalidation is needed, only order: the stores
+                // have completed before lane 0 announces them.  (A __threadfence() here writes back and invalidates
+                // the whole L2 per wave: 35 -> 103 us for the C2 launch.)
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                uint32_t first = 0;
+                if (lane == 0) first = __hip_atomic_fetch_add(&join_flag[jt], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                first = __builtin_amdgcn_readfirstlane(first);
+                if (first == 0u) return;               // the other part is still at work: it will join
+                asm volatile("" ::: "memory");
+                if (lane == 0) __hip_atomic_store(&join_flag[jt], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // for the next launch
+                const uint32_t o0 = __hip_atomic_load(theirs, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                const uint32_t o1 = __hip_atomic_load(theirs + 64, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                const uint32_t oo = __hip_atomic_load(theirs + 128, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                if (pid != 0xffffffffu) {
+                    const uint64_t mv = ((uint64_t)V[1] << 32) | V[0], ov = ((uint64_t)o1 << 32) | o0;
+                    const uint64_t Vf = back ? ov : mv, Vb = back ? mv : ov;
+                    const int S = 2 * kmax - (int)(n - m);                       // 47 or 48
+                    const uint64_t A = ~Vf, B = ~Vb & ((1ull << S) - 1ull);
+                    const uint64_t Br = __brevll(B) >> (64 - S);                 // bit x: row S - 1 - x of the back window
+                    const uint32_t a0 = (uint32_t)A, a1 = (uint32_t)(A >> 32), b0 = (uint32_t)Br, b1 = (uint32_t)(Br >> 32);
+                    int cur = __popcll(B), best = cur;                           // x = 0: nothing of the front window, S rows of the back one
+#pragma unroll
+                    for (int x = 0; x < 32; x++) { cur += (int)((a0 >> x) & 1u) - (int)((b0 >> x) & 1u); best = max(best, cur); }
+#pragma unroll
+                    for (int x = 0; x < MALCS_DIAG_HALF_T - 33; x++) { cur += (int)((a1 >> x) & 1u) - (int)((b1 >> x) & 1u); best = max(best, cur); }
+                    cur += (int)((a1 >> (MALCS_DIAG_HALF_T - 33)) & 1u) - (int)((b1 >> (MALCS_DIAG_HALF_T - 33)) & 1u);   // x = 47: only when S = 48
+                    if (S == MALCS_DIAG_HALF_T) best = max(best, cur);
+                    // zero bits of the rows that left either window (all inside the matrix but the kmax rows above it)
+                    const uint32_t zeros = n - ones - oo - 2u * (uint32_t)kmax + (uint32_t)best;
+                    d = (int32_t)(m + n - 2u * zeros);
+                    have_d = true;
+                }
+            } else {
+                banked = 32u * (uint32_t)iters - ones;
+                above = kmax;                          // rows above the matrix were banked as zeros
             }
         }
-        uint32_t w[NP];
+    }
+    if (!have_d) {
+        for (int it = halves ? iters : 0; it < iters;) {
+            if constexpr (NLW == 3 && NP == 2 && FUSED) {
+                auto plain3 = [&](int i) { return i + 3 <= iters && __builtin_amdgcn_ballot_w64(i + 3 > plain_hi) == 0; };
+                if (plain3(it)) {
+                    if (it == 0) above = kmax;                 // kmax <= 64: rows [-kmax, 0) lie in the first three leaving limbs
+                    diag_triples_dna3(V, P, banked, p, nxt, it, plain3);
+                    continue;
+                }
+            }
+            uint32_t w[NP];
 #pragma unroll
-        for (int q = 0; q < NP; q++) { P[NLW - 1][q] = nxt[q]; w[q] = nxt[NP + q]; }
-        V[NLW - 1] = ~0u;
-        p += 2 * NP * 64;                          // rows of the next block (the buffer ends with one block of padding)
-        const int hi = (int)n - 32 * it;           // one past the last valid step of the block: steps beyond must not change V
-        const uint32_t vm = hi >= 32 ? ~0u : (hi <= 0 ? 0u : ((1u << hi) - 1u));
-        const bool fast = __builtin_amdgcn_ballot_w64(vm != ~0u) == 0;
-        if constexpr (NLW == 3 && NP == 2 && FUSED) {
-            if (fast) {
-                diag_block_dna3(V, P, w, p, nxt);
-            } else {                               // last blocks of a pair
+            for (int q = 0; q < NP; q++) { P[NLW - 1][q] = nxt[q]; w[q] = nxt[NP + q]; }
+            V[NLW - 1] = ~0u;
+            p += 2 * NP * 64;                          // rows of the next block (the buffer ends with one block of padding)
+            const int hi = (int)n - 32 * it;           // one past the last valid step of the block: steps beyond must not change V
+            const uint32_t vm = hi >= 32 ? ~0u : (hi <= 0 ? 0u : ((1u << hi) - 1u));
+            const bool fast = __builtin_amdgcn_ballot_w64(vm != ~0u) == 0;
+            if constexpr (NLW == 3 && NP == 2 && FUSED) {
+                if (fast) {
+                    diag_block_dna3(V, P, w, p, nxt);
+                } else {                               // last blocks of a pair
+                    rows_load_async(p, nxt, std::make_integer_sequence<int, 2 * NP>());
+                    diag_block<NLW, NP, true>(V, P, w, vm, std::make_integer_sequence<int, 32 + NLW - 1>());
+                    rows_wait(nxt);
+                }
+            } else {
                 rows_load_async(p, nxt, std::make_integer_sequence<int, 2 * NP>());
-                diag_block<NLW, NP, true>(V, P, w, vm, std::make_integer_sequence<int, 32 + NLW - 1>());
+                if (fast) diag_block<NLW, NP, false>(V, P, w, vm, std::make_integer_sequence<int, 32 + NLW - 1>());
+                else      diag_block<NLW, NP, true>(V, P, w, vm, std::make_integer_sequence<int, 32 + NLW - 1>());
                 rows_wait(nxt);
             }
-        } else {
-            rows_load_async(p, nxt, std::make_integer_sequence<int, 2 * NP>());
-            if (fast) diag_block<NLW, NP, false>(V, P, w, vm, std::make_integer_sequence<int, 32 + NLW - 1>());
-            else      diag_block<NLW, NP, true>(V, P, w, vm, std::make_integer_sequence<int, 32 + NLW - 1>());
-            rows_wait(nxt);
-        }
-        // the window moves down one limb
-        banked += __popc(~V[0] & rowmask(32 * it - kmax));
+            // the window moves down one limb
+            banked += __popc(~V[0] & rowmask(32 * it - kmax));
 #pragma unroll
-        for (int k = 0; k < NLW - 1; k++) {
-            V[k] = V[k + 1];
+            for (int k = 0; k < NLW - 1; k++) {
+                V[k] = V[k + 1];
 #pragma unroll
-            for (int q = 0; q < NP; q++) P[k][q] = P[k + 1][q];
+                for (int q = 0; q < NP; q++) P[k][q] = P[k + 1][q];
+            }
+            it++;
         }
-        it++;
+        uint32_t zeros = banked - (uint32_t)above;
+#pragma unroll
+        for (int k = 0; k < NLW - 1; k++) zeros += __popc(~V[k] & rowmask(32 * (iters + k) - kmax));
+        d = (int32_t)(m + n - 2u * zeros);
     }
-    uint32_t zeros = banked - (uint32_t)above;
-#pragma unroll
-    for (int k = 0; k < NLW - 1; k++) zeros += __popc(~V[k] & rowmask(32 * (iters + k) - kmax));
 
     if (pid != 0xffffffffu) {
-        const int32_t d = (int32_t)(m + n - 2u * zeros);
         if (d <= (halves ? MALCS_DIAG_HALF_T : T)) {
             dist[pid] = d;
         } else {
@@ -582,8 +756,8 @@ k_llcs_diag(const uint32_t *__restrict__ rows, const uint32_t *__restrict__ tile
     }
 }
 
-typedef void (*diag_kernel_t)(const uint32_t *, const uint32_t *, const uint32_t *, int32_t *, uint32_t *,
-                              const uint32_t *, const uint32_t *, uint32_t *, uint32_t *, uint32_t);
+typedef void (*diag_kernel_t)(const uint32_t *, const uint32_t *, const uint32_t *, const uint32_t *, int32_t *, uint32_t *,
+                              const uint32_t *, const uint32_t *, uint32_t *, uint32_t *, uint32_t, uint32_t *, uint32_t *);
 template <int NP>
 diag_kernel_t pick_diag(int nlw)
 {
@@ -604,12 +778,20 @@ int malcs_diag_threshold(int nlw) { return 32 * nlw - 32; }
 void malcs_diag_release(malcs_batch *b)
 {
     diag_plan &d = b->diag;
-    hipFree(d.d_rows);                   // the other arrays of the plan are parts of this allocation
+    if (d.d_rows) malcs_pool_free(b->ctx, d.d_rows);          // the other arrays of the plan are parts of this allocation
     d = diag_plan();
 }
 
+// Everything the plan of a batch's window class needs, in the order it happens:
+//   1. (device) k_plan_ends: common ends, what is left of every pair, histogram of block counts;
+//      a sample of the pairs goes through the full-matrix kernel, whose distances decide the mode of the class;
+//   2. one copy back (histogram + sample), the plan's only synchronisation;
+//   3. (host, from the histogram alone) tiles of 64 pairs of equal length, their mode, their pieces: which tiles are
+//      cut and where, which piece runs as which workgroup, where its rows start;
+//   4. (device) k_plan_scatter puts the pairs into their slots, k_diag_layout writes the rows.
+// Nothing after step 2 waits: the launch that follows is ordered behind the plan by the stream.
 static int plan_window(malcs_batch *b, int nlw, const std::vector<uint32_t> &pairs, const std::vector<uint8_t> &retry_class,
-                       const std::vector<diag_retry> &classes, bool half_mode)
+                       const std::vector<diag_retry> &classes)
 {
     diag_plan &d = b->diag;
     d = diag_plan();
@@ -618,99 +800,164 @@ static int plan_window(malcs_batch *b, int nlw, const std::vector<uint32_t> &pai
         malcs_set_error("no window kernel for %d limbs and %d bit planes", nlw, b->n_planes);
         return MALCS_ERR_INTERNAL;
     }
+    malcs_ctx *ctx = b->ctx;
+    hipStream_t st = ctx->stream;
     const int T = malcs_diag_threshold(nlw);
     malcs_stage_trace trace("window plan");
-    // Common ends do not change the distance (the reference's sweep slides through them in one snake, LCSgraph.from_sequence
-    // cuts them off with trim(), lcs_graph.py:231-235): they are left out of the window (the layout kernel shifts pattern and
-    // text by what is cut in front), as long as enough rows for the window class remain.  Needs the caller's symbols, so
-    // only at batch creation; MALCS_DIAG_TRIM=0 switches it off.
-    const bool trim = b->raw_syms && !(getenv("MALCS_DIAG_TRIM") && atoi(getenv("MALCS_DIAG_TRIM")) == 0);
-    const uint32_t min_rows = 32u * (2u * (uint32_t)nlw + 2u);
+    const uint32_t count = (uint32_t)pairs.size();
     const uint32_t NP = (uint32_t)b->n_planes;
-    struct item { uint32_t pid, delta, cls, iters, po, to, m, n, q, mt, nt; };
-    std::vector<item> items(pairs.size());
-    std::atomic<uint32_t> misfit{0xffffffffu};
-    auto plan_items = [&](size_t first, size_t last) {
-        for (size_t i = first; i < last; i++) {
-            const uint32_t pid = pairs[i];
-            const bool a_short = b->a_len[pid] <= b->b_len[pid];
-            uint32_t m = a_short ? b->a_len[pid] : b->b_len[pid], n = a_short ? b->b_len[pid] : b->a_len[pid];
-            uint32_t po = a_short ? b->a_off[pid] : b->b_off[pid], to = a_short ? b->b_off[pid] : b->a_off[pid];
-            uint32_t q = 0, mt = m, nt = n;
-            const int delta = (int)(n - m);
-            if (delta > T || n == 0) { misfit.store(pid); return; }
-            if (trim && m > min_rows) {
-                const uint8_t *x = b->raw_syms + (a_short ? b->raw_a_off[pid] : b->raw_b_off[pid]);     // pattern, m symbols
-                const uint8_t *y = b->raw_syms + (a_short ? b->raw_b_off[pid] : b->raw_a_off[pid]);     // text, n symbols
-                const uint32_t room = m - min_rows;
-                uint32_t pre = 0;
-                while (pre + 8 <= room) {                    // eight symbols at a time
-                    uint64_t wx, wy;
-                    memcpy(&wx, x + pre, 8); memcpy(&wy, y + pre, 8);
-                    if (wx != wy) break;
-                    pre += 8;
-                }
-                while (pre < room && x[pre] == y[pre]) pre++;
-                uint32_t suf = 0;
-                const uint8_t *xe = x + m, *ye = y + n;
-                while (suf + 8 <= room - pre) {
-                    uint64_t wx, wy;
-                    memcpy(&wx, xe - suf - 8, 8); memcpy(&wy, ye - suf - 8, 8);
-                    if (wx != wy) break;
-                    suf += 8;
-                }
-                while (suf < room - pre && xe[-1 - (ptrdiff_t)suf] == ye[-1 - (ptrdiff_t)suf]) suf++;
-                po += (pre >> 5) * NP; to += (pre >> 5) * NP; q = pre & 31u;
-                m -= pre + suf; n -= pre + suf;
-                mt = q + m + suf; nt = q + n + suf;
-            }
-            // a text of whole blocks has no masked last block: both sequences grow by the same symbols at the end (what
-            // was cut off there first, symbol 0 beyond the end: see k_diag_layout)
-            const uint32_t ragged = (32u - (n & 31u)) & 31u;
-            m += ragged; n += ragged;
-            items[i] = {pid, (uint32_t)delta, retry_class[i], (n + 31u) / 32u, po, to, m, n, q, mt, nt};
+    // MALCS_DIAG_TRIM=0 keeps the common ends inside the window
+    const int trim = !(getenv("MALCS_DIAG_TRIM") && atoi(getenv("MALCS_DIAG_TRIM")) == 0);
+    const uint32_t min_rows = 32u * (2u * (uint32_t)nlw + 2u);
+    uint32_t max_len = 0;
+    for (uint32_t pid : pairs) {
+        const uint32_t mx = std::max(b->a_len[pid], b->b_len[pid]), mn = std::min(b->a_len[pid], b->b_len[pid]);
+        if (mx - mn > (uint32_t)T || mx == 0) { malcs_set_error("pair %u does not fit the window class", pid); return MALCS_ERR_INTERNAL; }
+        max_len = std::max(max_len, mx);
+    }
+    const uint32_t HB = (max_len + 31u) / 32u + 2u;          // histogram bins per group: block counts 0 ... HB - 1
+
+    // ---- 1. device: ends, items, histogram; the sample -------------------------------------------------
+    const bool can_half = nlw == 3 && NP == 2 && !getenv("MALCS_DIAG_GENERIC");
+    bool half_mode = false, sampled = false;
+    std::vector<uint32_t> sample;
+    if (can_half) {
+        const char *env = getenv("MALCS_DIAG_HALF");
+        if (env && *env) half_mode = atoi(env) != 0;
+        else if (count >= 4096) {
+            // two limbs (T = 48, a quarter less work) when no distance of a sample of about a thousand pairs comes near
+            // the threshold: whatever exceeds it is redone over the full matrix, at ten times the cost of a window
+            sampled = true;
+            const size_t stride = count / 1024;
+            for (size_t i = stride / 2; i < count; i += stride) sample.push_back((uint32_t)i);
         }
-    };
-    {
-        // the scan of the ends is a cache miss or two per sequence: threads from a few thousand pairs on
-        const size_t nt = pairs.size() < 4096 ? 1 : std::min<size_t>(16, std::max(1u, std::thread::hardware_concurrency()));
-        std::vector<std::thread> pool;
-        size_t started = 1;                                 // shares [0, started) of nt are taken
-        try {
-            for (; started < nt; started++) pool.emplace_back(plan_items, pairs.size() * started / nt, pairs.size() * (started + 1) / nt);
-        } catch (const std::system_error &) {}              // no more threads to be had: this one does the rest
-        plan_items(0, pairs.size() / nt);
-        if (started < nt) plan_items(pairs.size() * started / nt, pairs.size());
-        for (std::thread &t : pool) t.join();
     }
-    if (misfit.load() != 0xffffffffu) { malcs_set_error("pair %u does not fit the window class", misfit.load()); return MALCS_ERR_INTERNAL; }
-    trace.lap("common ends");
-    // tiles of equal length: a stable counting sort by the number of blocks
-    {
-        uint32_t max_it = 0;
-        for (const item &x : items) max_it = std::max(max_it, x.iters);
-        std::vector<size_t> start((size_t)max_it + 2, 0);
-        for (const item &x : items) start[(size_t)x.iters + 1]++;
-        for (size_t k = 1; k < start.size(); k++) start[k] += start[k - 1];
-        std::vector<item> sorted(items.size());
-        for (const item &x : items) sorted[start[x.iters]++] = x;
-        items.swap(sorted);
+    size_t temp_dw = 0;
+    auto carve = [](size_t &total, size_t dwords) { const size_t at = total; total += (dwords + 63) & ~(size_t)63; return at; };
+    const size_t at_pairs = carve(temp_dw, count), at_cls = carve(temp_dw, (count + 3) / 4), at_item = carve(temp_dw, (size_t)ITEM_FIELDS * count);
+    const size_t at_hist = carve(temp_dw, 2 * (size_t)HB), at_slot = carve(temp_dw, (size_t)((count + 63) / 64) * 64);
+    const size_t at_sample = carve(temp_dw, 2 * sample.size() + 1), at_scount = carve(temp_dw, 64);
+    pool_scoped<uint32_t> temp(ctx);
+    MALCS_HIP(temp.alloc(temp_dw));
+    uint32_t *const d_pairs = temp.p + at_pairs, *const d_item = temp.p + at_item, *const d_hist = temp.p + at_hist;
+    uint32_t *const d_slot = temp.p + at_slot, *const d_sample = temp.p + at_sample, *const d_scount = temp.p + at_scount;
+    uint8_t *const d_cls = reinterpret_cast<uint8_t *>(temp.p + at_cls);
+    MALCS_HIP(malcs_h2d(st, d_pairs, pairs.data(), count * sizeof(uint32_t)));
+    MALCS_HIP(malcs_h2d(st, d_cls, retry_class.data(), count));
+    MALCS_HIP(hipMemsetAsync(d_hist, 0, 2 * (size_t)HB * sizeof(uint32_t), st));
+    const dim3 g256((count + 255u) / 256u), b256(256);
+    switch (NP) {
+    case 2: hipLaunchKernelGGL(k_plan_ends<2>, g256, b256, 0, st, b->d_planes, b->d_a_off, b->d_a_len, b->d_b_off, b->d_b_len, d_pairs, count, min_rows, trim, HB, d_item, d_hist); break;
+    case 3: hipLaunchKernelGGL(k_plan_ends<3>, g256, b256, 0, st, b->d_planes, b->d_a_off, b->d_a_len, b->d_b_off, b->d_b_len, d_pairs, count, min_rows, trim, HB, d_item, d_hist); break;
+    case 4: hipLaunchKernelGGL(k_plan_ends<4>, g256, b256, 0, st, b->d_planes, b->d_a_off, b->d_a_len, b->d_b_off, b->d_b_len, d_pairs, count, min_rows, trim, HB, d_item, d_hist); break;
     }
-    const uint32_t n_tiles = (uint32_t)((items.size() + 63) / 64);
-    std::vector<uint32_t> tile_pid((size_t)n_tiles * 64, 0xffffffffu), tile_kc((size_t)n_tiles * 64, 0u);
-    std::vector<uint32_t> tile_seq((size_t)n_tiles * 64 * 7, 0u);          // po, to, m, n, q, mt, nt of every slot (seven arrays back to back)
-    const size_t slots = (size_t)n_tiles * 64;
-    std::vector<uint32_t> tile_off(n_tiles + 1), tile_iters(n_tiles);
-    // Which tile runs as which workgroup.  All workgroups of a launch are resident at once, and the dispatcher deals
-    // them round-robin: workgroups p and p + S share a SIMD (S = SIMDs of the device; tools/wave_placement.hip: every one
-    // of the 539 two-wave SIMDs of a 1 563-wave launch holds indices 1 024 apart).  A launch ends with its most loaded
-    // SIMD, so the tiles (sorted by length above) are dealt longest first to the SIMD with the least work so far among
-    // those with a free slot, SIMDs with fewer slots first: at C2 the 485 SIMDs with one wave get the longest tiles and
-    // the others a long and a short one each.
-    std::vector<uint32_t> tile_at(n_tiles);                    // workgroup index -> tile (in sorted order)
-    std::vector<uint8_t> tile_half(n_tiles, 0);
+    MALCS_HIP(hipGetLastError());
+    std::vector<int32_t> sample_dist(sample.size(), 0);
+    if (sampled) {
+        // the sampled pairs, grouped by their full-matrix class, through k_llcs_bitpar_list (exact distances into d_dist,
+        // where the real launch overwrites them later)
+        std::vector<uint32_t> list(sample.size()), first(classes.size() + 1, 0), fill(classes.size(), 0);
+        for (uint32_t i : sample) first[retry_class[i] + 1]++;
+        for (size_t c = 0; c < classes.size(); c++) first[c + 1] += first[c];
+        for (uint32_t i : sample) { const uint8_t c = retry_class[i]; list[first[c] + fill[c]++] = pairs[i]; }
+        MALCS_HIP(malcs_h2d(st, d_sample, list.data(), list.size() * sizeof(uint32_t)));
+        MALCS_HIP(malcs_h2d(st, d_scount, fill.data(), fill.size() * sizeof(uint32_t)));
+        for (size_t c = 0; c < classes.size(); c++) {
+            if (!fill[c]) continue;
+            const uint32_t ppw = 64u / (uint32_t)classes[c].L;
+            const int rc = malcs_dist_launch_list(st, b->n_planes, classes[c].W, classes[c].L, b->d_planes, b->d_a_off, b->d_a_len, b->d_b_off,
+                                                  b->d_b_len, d_sample, first[c], d_scount + c, fill[c], (fill[c] + ppw - 1u) / ppw, b->d_dist);
+            if (rc) return rc;
+        }
+        hipLaunchKernelGGL(k_plan_gather, dim3(((uint32_t)list.size() + 255u) / 256u), b256, 0, st, b->d_dist, d_sample, (uint32_t)list.size(),
+                           reinterpret_cast<int32_t *>(d_sample + list.size()));
+        MALCS_HIP(hipGetLastError());
+        MALCS_HIP(malcs_d2h(st, sample_dist.data(), d_sample + list.size(), list.size() * sizeof(int32_t)));
+    }
+    // ---- 2. the one copy back ----------------------------------------------------------------------------
+    std::vector<uint32_t> hist(2 * (size_t)HB);
+    MALCS_HIP(malcs_d2h(st, hist.data(), d_hist, hist.size() * sizeof(uint32_t)));
+    MALCS_HIP(malcs_sync(st));
+    trace.lap("ends, histogram, sample (device) + copy back");
+    if (sampled) {
+        int32_t worst = 0;
+        for (int32_t x : sample_dist) worst = std::max(worst, x);
+        half_mode = worst <= MALCS_DIAG_HALF_T - 6;
+    }
+
+    // ---- 3. host: tiles and pieces from the histogram ----------------------------------------------------
+    // Sorted order of the slots: by blocks, ascending; in two-limb mode the pairs whose length difference that mode
+    // cannot hold come last, as a group of their own (their tiles run with three limbs).  `start` is the exclusive scan
+    // of the histogram in that order = the cursors of the scatter kernel.
+    std::vector<uint32_t> start(2 * (size_t)HB);
+    std::vector<uint32_t> key_order;                           // keys with pairs, in sorted order
     {
-        const uint32_t S = std::max(1, b->ctx->prop.multiProcessorCount) * 4u;
+        uint32_t acc = 0;
+        auto take = [&](uint32_t key) { start[key] = acc; if (hist[key]) key_order.push_back(key); acc += hist[key]; };
+        if (half_mode) { for (uint32_t g = 0; g < 2; g++) for (uint32_t it = 0; it < HB; it++) take(g * HB + it); }
+        else           { for (uint32_t it = 0; it < HB; it++) for (uint32_t g = 0; g < 2; g++) take(g * HB + it); }
+        if (acc != count) { malcs_set_error("window plan: histogram holds %u of %u pairs", acc, count); return MALCS_ERR_INTERNAL; }
+    }
+    const uint32_t n_tiles = (count + 63u) / 64u;
+    std::vector<uint32_t> tile_iters(n_tiles);                 // blocks of the tile's longest pair | half << 31
+    uint64_t cells = 0;
+    uint32_t n_half = 0;
+    {
+        size_t k = 0;                                          // walks key_order
+        uint32_t used = 0;                                     // pairs of key_order[k] already placed
+        for (uint32_t t = 0; t < n_tiles; t++) {
+            const uint32_t want = std::min(64u, count - t * 64u);
+            uint32_t have = 0, longest = 1;
+            bool half = half_mode;
+            while (have < want) {
+                const uint32_t key = key_order[k], avail = hist[key] - used, take = std::min(avail, want - have);
+                longest = std::max(longest, key % HB);
+                half = half && key < HB;
+                have += take; used += take;
+                if (used == hist[key]) { k++; used = 0; }
+            }
+            tile_iters[t] = longest | (half ? 0x80000000u : 0u);
+            n_half += half;
+            cells += (uint64_t)(half ? 64 : 32 * nlw) * 32u * longest * want;
+        }
+    }
+    // Pieces.  All workgroups of a launch are resident at once and the dispatcher deals them round-robin: workgroups w
+    // and w' share a SIMD iff w = w' (mod #SIMDs) (tools/wave_placement.hip, up to four waves per SIMD).  A launch ends
+    // with its most loaded SIMD, and a wave alone on a SIMD issues at two thirds of the rate two or three waves reach
+    // together (5.3 against 3.4 / 3.2 clk per instruction), so what a SIMD holds should be equally long and run side by
+    // side.  A tile in two-limb mode can be cut once, anywhere (see the kernel): every such tile is cut in the middle,
+    // which doubles the waves of a launch, and the pieces are dealt longest first to the SIMD with the least work so far
+    // among those with a free slot, SIMDs with fewer slots first -- at C2 (1 563 tiles, 3 126 pieces, 1 024 SIMDs) the 970
+    // SIMDs with three waves get the halves of the longest tiles, the 54 with four the halves of the shortest.  (Laying
+    // the tiles end to end and cutting the line into one stretch per SIMD balances the blocks exactly, but leaves
+    // a SIMD with pieces of different length, the longest of which ends up running alone: 37.4 against 34.2 us uncut.)
+    // Beyond four pieces per SIMD the hardware cannot hold all waves at once and balances by itself: no cuts then.
+    // MALCS_DIAG_CUT=0 / 1: never / always.
+    struct piece { uint32_t tile, blocks, flags, join; };
+    const uint32_t S = std::max(1, ctx->prop.multiProcessorCount) * 4u;
+    bool cut = n_half > 0 && 2u * n_tiles <= 4u * S;
+    if (const char *env = getenv("MALCS_DIAG_CUT")) if (*env) cut = n_half > 0 && atoi(env) != 0;
+    std::vector<piece> pieces;
+    uint32_t n_joins = 0;
+    {
+        std::vector<piece> todo;                               // most expensive first (the tiles are sorted by length)
+        todo.reserve(2 * (size_t)n_tiles);
+        for (uint32_t r = 0; r < n_tiles; r++) {
+            const uint32_t t = n_tiles - 1u - r, it = tile_iters[t] & 0x7fffffffu;
+            const bool half = tile_iters[t] >> 31;
+            if (cut && half && it >= 4) {
+                const uint32_t c = std::min(it - 2u, std::max(2u, (it + 1u) / 2u));
+                todo.push_back({t, c, PIECE_HALF | PIECE_JOINED, n_joins});
+                todo.push_back({t, it - c, PIECE_HALF | PIECE_JOINED | PIECE_BACK, n_joins});
+                n_joins++;
+            } else {
+                todo.push_back({t, it, half ? PIECE_HALF : 0u, 0u});
+            }
+        }
+        // cost in sixteenths of a three-limb block; a block in two-limb mode costs 0.74
+        auto cost = [](const piece &x) -> uint32_t { return x.blocks * ((x.flags & PIECE_HALF) ? 12u : 16u); };
+        std::stable_sort(todo.begin(), todo.end(), [&](const piece &x, const piece &y) { return cost(x) > cost(y); });
+        const uint32_t n = (uint32_t)todo.size();
         struct simd_load { uint64_t load; uint32_t slots, used, idx; };
         auto worse = [](const simd_load &x, const simd_load &y) {   // priority queue: top = least load, then fewest slots
             if (x.load != y.load) return x.load > y.load;
@@ -718,152 +965,89 @@ static int plan_window(malcs_batch *b, int nlw, const std::vector<uint32_t> &pai
             return x.idx > y.idx;
         };
         std::vector<simd_load> heap;
-        for (uint32_t i = 0; i < std::min(S, n_tiles); i++) heap.push_back({0, (n_tiles - i + S - 1) / S, 0, i});
+        for (uint32_t i = 0; i < std::min(S, n); i++) heap.push_back({0, (n - i + S - 1) / S, 0, i});
         std::make_heap(heap.begin(), heap.end(), worse);
-        // cost of a tile in sixteenths of a three-limb block; a block in two-limb mode costs 0.74.  Two-limb mode
-        // (MALCS_DIAG_HALF=1): tiles whose lanes all have a length difference the narrower band holds.
-        std::vector<std::pair<uint32_t, uint32_t>> by_cost(n_tiles);
-        for (uint32_t j = 0; j < n_tiles; j++) {
-            const size_t i0 = (size_t)j * 64, i1 = std::min(items.size(), i0 + 64);
-            // the lanes of a tile run in step: the shorter texts of a tile grow to its longest by whole blocks (again the
-            // same symbols on both sequences), so that no lane has masked blocks while the others still work
-            uint32_t longest = 0;
-            for (size_t i = i0; i < i1; i++) longest = std::max(longest, items[i].n);
-            bool half = half_mode;
-            for (size_t i = i0; i < i1; i++) {
-                const uint32_t grow = longest - items[i].n;
-                items[i].m += grow; items[i].n += grow; items[i].iters = items[i].n / 32u;
-                half = half && items[i].delta <= (uint32_t)MALCS_DIAG_HALF_T;
-            }
-            const uint32_t it = std::max(1u, longest / 32u);
-            tile_half[j] = half;
-            by_cost[j] = {half ? 12u * it : 16u * it, j};
-        }
-        std::sort(by_cost.begin(), by_cost.end(), [](const std::pair<uint32_t, uint32_t> &x, const std::pair<uint32_t, uint32_t> &y) {
-            return x.first != y.first ? x.first > y.first : x.second < y.second;
-        });
-        for (uint32_t r = 0; r < n_tiles; r++) {               // most expensive first
+        pieces.resize(n);
+        for (uint32_t r = 0; r < n; r++) {
             std::pop_heap(heap.begin(), heap.end(), worse);
             simd_load &top = heap.back();
-            tile_at[top.idx + top.used * S] = by_cost[r].second;
-            top.used++; top.load += by_cost[r].first;
+            pieces[top.idx + top.used * S] = todo[r];
+            top.used++; top.load += cost(todo[r]);
             if (top.used == top.slots) heap.pop_back(); else std::push_heap(heap.begin(), heap.end(), worse);
         }
     }
-    uint64_t row = 0, cells = 0;
-    uint32_t max_rows = 0;
-    for (uint32_t t = 0; t < n_tiles; t++) {
-        uint32_t it = 1;
-        const size_t j0 = (size_t)tile_at[t] * 64, s0 = (size_t)t * 64;
-        const bool half = tile_half[tile_at[t]];
-        const int Tm = half ? MALCS_DIAG_HALF_T : T;
-        for (size_t i = j0; i < std::min(items.size(), j0 + 64); i++) {
-            const size_t k = s0 + (i - j0);
-            const int kmax = (int)items[i].delta + (Tm - (int)items[i].delta) / 2;
-            tile_pid[k] = items[i].pid; tile_kc[k] = (uint32_t)kmax | (items[i].cls << 16); it = std::max(it, items[i].iters);
-            tile_seq[k] = items[i].po; tile_seq[slots + k] = items[i].to; tile_seq[2 * slots + k] = items[i].m; tile_seq[3 * slots + k] = items[i].n; tile_seq[4 * slots + k] = items[i].q; tile_seq[5 * slots + k] = items[i].mt; tile_seq[6 * slots + k] = items[i].nt;
-            cells += (uint64_t)(half ? 64 : 32 * nlw) * items[i].n;
-        }
-        tile_off[t] = (uint32_t)row; tile_iters[t] = it | (half ? 0x80000000u : 0u);
-        const uint32_t r = (uint32_t)(nlw - 1) + it;
-        max_rows = std::max(max_rows, r);
-        row += (uint64_t)META_ROWS + (uint64_t)(nlw - 1) * b->n_planes + (uint64_t)it * 2u * b->n_planes;
+    const uint32_t n_pieces = (uint32_t)pieces.size();
+    std::vector<uint32_t> piece_tab((size_t)4 * n_pieces + 1);      // off[n_pieces + 1], info, tile, join
+    uint64_t row = 0;
+    for (uint32_t i = 0; i < n_pieces; i++) {
+        piece_tab[i] = (uint32_t)row;
+        piece_tab[n_pieces + 1 + i] = pieces[i].blocks | pieces[i].flags;
+        piece_tab[2 * (size_t)n_pieces + 1 + i] = pieces[i].tile;
+        piece_tab[3 * (size_t)n_pieces + 1 + i] = pieces[i].join;
+        row += (uint64_t)META_ROWS + (uint64_t)(nlw - 1) * NP + (uint64_t)pieces[i].blocks * 2u * NP;
         if (row >= 0xffffffffull) { malcs_set_error("window class too large; split the batch"); return MALCS_ERR_TOO_LONG; }
     }
-    tile_off[n_tiles] = (uint32_t)row;
+    piece_tab[n_pieces] = (uint32_t)row;
+    trace.lap("tiles, pieces (host)");
 
-    trace.lap("sort, deal, tile arrays");
     // retry bookkeeping: one list segment per full-matrix class, sized for the worst case
     d.retry = classes;
     std::vector<uint32_t> cap(classes.size(), 0), first(classes.size(), 0);
-    for (size_t i = 0; i < pairs.size(); i++) cap[retry_class[i]]++;
+    for (uint32_t i = 0; i < count; i++) cap[retry_class[i]]++;
     uint32_t acc = 0;
     for (size_t c = 0; c < classes.size(); c++) { first[c] = acc; acc += cap[c]; d.retry[c].first = first[c]; d.retry[c].cap = cap[c]; }
 
-    hipStream_t st = b->ctx->stream;
+    // ---- 4. device: slots, rows ----------------------------------------------------------------------------
     const size_t ncls = std::max<size_t>(classes.size(), 1);
-    // one allocation for everything that lives as long as the plan, one for what only the layout kernel reads
-    // (an allocation costs a fraction of a millisecond; dwords, every array on a 256-byte boundary)
-    size_t keep = 0, temp = 0;
-    auto carve = [](size_t &total, size_t dwords) { const size_t at = total; total += (dwords + 63) & ~(size_t)63; return at; };
-    const size_t at_rows = carve(keep, ((size_t)row + 2u * b->n_planes) * 64u);     // + one block of padding: the kernel prefetches unconditionally
-    const size_t at_off = carve(keep, n_tiles + 1), at_iters = carve(keep, n_tiles);
+    size_t keep = 0;
+    const size_t at_rows = carve(keep, ((size_t)row + 2u * NP) * 64u);     // + one block of padding: the kernel prefetches unconditionally
+    const size_t at_tab = carve(keep, piece_tab.size());
     const size_t at_list = carve(keep, std::max<uint32_t>(acc, 1)), at_first = carve(keep, ncls), at_cap = carve(keep, ncls);
-    const size_t at_count = carve(keep, 2 * ncls);                                  // two sets, used by alternate launches
-    const size_t at_pid = carve(temp, tile_pid.size()), at_kc = carve(temp, tile_kc.size()), at_seq = carve(temp, tile_seq.size());
-    MALCS_HIP(hipMalloc(&d.d_rows, keep * sizeof(uint32_t)));
-    d.d_tile_off = d.d_rows + at_off; d.d_tile_iters = d.d_rows + at_iters; d.d_retry_list = d.d_rows + at_list;
-    d.d_retry_first = d.d_rows + at_first; d.d_retry_cap = d.d_rows + at_cap; d.d_retry_count = d.d_rows + at_count;
-    (void)at_rows;                                                                  // the rows come first: d_rows is the allocation
-    dev_scoped<uint32_t> temp_dev;
-    MALCS_HIP(hipMalloc(&temp_dev.p, temp * sizeof(uint32_t)));
-    uint32_t *const d_tile_pid = temp_dev.p + at_pid, *const d_tile_kc = temp_dev.p + at_kc, *const d_tile_seq = temp_dev.p + at_seq;
-    MALCS_HIP(malcs_h2d(st, d.d_tile_off, tile_off.data(), (n_tiles + 1) * sizeof(uint32_t)));
-    MALCS_HIP(malcs_h2d(st, d.d_tile_iters, tile_iters.data(), n_tiles * sizeof(uint32_t)));
-    MALCS_HIP(malcs_h2d(st, d_tile_pid, tile_pid.data(), tile_pid.size() * sizeof(uint32_t)));
-    MALCS_HIP(malcs_h2d(st, d_tile_kc, tile_kc.data(), tile_kc.size() * sizeof(uint32_t)));
-    MALCS_HIP(malcs_h2d(st, d_tile_seq, tile_seq.data(), tile_seq.size() * sizeof(uint32_t)));
+    const size_t at_count = carve(keep, 2 * ncls);                         // two sets, used by alternate launches
+    const size_t at_jbuf = carve(keep, (size_t)n_joins * 384u), at_jflag = carve(keep, std::max(n_joins, 1u));
+    const size_t at_titers = carve(keep, n_tiles);
+    MALCS_HIP(malcs_pool_alloc(ctx, (void **)&d.d_rows, keep * sizeof(uint32_t)));
+    (void)at_rows;                                                         // the rows come first: d_rows is the allocation
+    uint32_t *const tab = d.d_rows + at_tab;
+    d.d_piece_off = tab; d.d_piece_info = tab + n_pieces + 1; d.d_piece_join = tab + 3 * (size_t)n_pieces + 1;
+    uint32_t *const d_piece_tile = tab + 2 * (size_t)n_pieces + 1, *const d_tile_iters = d.d_rows + at_titers;
+    d.d_retry_list = d.d_rows + at_list; d.d_retry_first = d.d_rows + at_first; d.d_retry_cap = d.d_rows + at_cap;
+    d.d_retry_count = d.d_rows + at_count; d.d_join_buf = d.d_rows + at_jbuf; d.d_join_flag = d.d_rows + at_jflag;
+    MALCS_HIP(malcs_h2d(st, tab, piece_tab.data(), piece_tab.size() * sizeof(uint32_t)));
+    MALCS_HIP(malcs_h2d(st, d_tile_iters, tile_iters.data(), n_tiles * sizeof(uint32_t)));
+    MALCS_HIP(malcs_h2d(st, d_hist, start.data(), start.size() * sizeof(uint32_t)));          // the histogram becomes the cursors
     if (!classes.empty()) {
         MALCS_HIP(malcs_h2d(st, d.d_retry_first, first.data(), classes.size() * sizeof(uint32_t)));
         MALCS_HIP(malcs_h2d(st, d.d_retry_cap, cap.data(), classes.size() * sizeof(uint32_t)));
     }
     MALCS_HIP(hipMemsetAsync(d.d_retry_count, 0, 2 * ncls * sizeof(uint32_t), st));
-    const dim3 grid(max_rows, n_tiles), block(64);
-    switch (b->n_planes) {
-    case 2: hipLaunchKernelGGL(k_diag_layout<2>, grid, block, 0, st, b->d_planes, d_tile_seq, d_tile_seq + slots, d_tile_seq + 2 * slots, d_tile_seq + 3 * slots, d_tile_seq + 4 * slots, d_tile_seq + 5 * slots, d_tile_seq + 6 * slots, d_tile_pid, d_tile_kc, d.d_tile_off, d.d_tile_iters, nlw, d.d_rows); break;
-    case 3: hipLaunchKernelGGL(k_diag_layout<3>, grid, block, 0, st, b->d_planes, d_tile_seq, d_tile_seq + slots, d_tile_seq + 2 * slots, d_tile_seq + 3 * slots, d_tile_seq + 4 * slots, d_tile_seq + 5 * slots, d_tile_seq + 6 * slots, d_tile_pid, d_tile_kc, d.d_tile_off, d.d_tile_iters, nlw, d.d_rows); break;
-    case 4: hipLaunchKernelGGL(k_diag_layout<4>, grid, block, 0, st, b->d_planes, d_tile_seq, d_tile_seq + slots, d_tile_seq + 2 * slots, d_tile_seq + 3 * slots, d_tile_seq + 4 * slots, d_tile_seq + 5 * slots, d_tile_seq + 6 * slots, d_tile_pid, d_tile_kc, d.d_tile_off, d.d_tile_iters, nlw, d.d_rows); break;
+    MALCS_HIP(hipMemsetAsync(d.d_join_flag, 0, std::max(n_joins, 1u) * sizeof(uint32_t), st));
+    MALCS_HIP(hipMemsetAsync(d_slot, 0xff, (size_t)n_tiles * 64u * sizeof(uint32_t), st));
+    hipLaunchKernelGGL(k_plan_scatter, g256, b256, 0, st, d_item, count, HB, d_hist, d_slot);
+    switch (NP) {
+    case 2: hipLaunchKernelGGL(k_diag_layout<2>, dim3(n_pieces), b256, 0, st, b->d_planes, d_item, count, d_pairs, d_cls, d_slot, d_tile_iters, d.d_piece_off, d.d_piece_info, d_piece_tile, nlw, T, d.d_rows); break;
+    case 3: hipLaunchKernelGGL(k_diag_layout<3>, dim3(n_pieces), b256, 0, st, b->d_planes, d_item, count, d_pairs, d_cls, d_slot, d_tile_iters, d.d_piece_off, d.d_piece_info, d_piece_tile, nlw, T, d.d_rows); break;
+    case 4: hipLaunchKernelGGL(k_diag_layout<4>, dim3(n_pieces), b256, 0, st, b->d_planes, d_item, count, d_pairs, d_cls, d_slot, d_tile_iters, d.d_piece_off, d.d_piece_info, d_piece_tile, nlw, T, d.d_rows); break;
     }
     MALCS_HIP(hipGetLastError());
-    MALCS_HIP(malcs_sync(st));           // the host vectors above are locals
-    trace.lap("allocations, copies, layout kernel");
-    d.nlw = nlw; d.T = T; d.n_tiles = n_tiles; d.n_pairs = (uint32_t)pairs.size(); d.window_cells = cells;
-    for (uint32_t j = 0; j < n_tiles; j++) d.n_half_tiles += tile_half[j];
+    // copies of more than a megabyte do not go through the staging buffer: their sources (locals) must outlive them
+    if ((size_t)count * sizeof(uint32_t) > (1u << 20) || piece_tab.size() * sizeof(uint32_t) > (1u << 20)) MALCS_HIP(malcs_sync(st));
+    trace.lap("slots, rows (device, queued)");
+    d.nlw = nlw; d.T = T; d.n_tiles = n_tiles; d.n_pairs = count; d.window_cells = cells;
+    d.n_half_tiles = n_half; d.n_pieces = n_pieces; d.n_cut_tiles = n_joins;
     if (d.n_half_tiles == n_tiles) d.T = MALCS_DIAG_HALF_T;    // what the plan reports: the threshold of every tile
     return MALCS_OK;
 }
 
-// The window class of a batch.  Three limbs (T = 64) unless the batch is similar enough for two (T = 48, a quarter less
-// work): MALCS_DIAG_HALF=0 / 1 decides by hand; otherwise a sample of about a thousand pairs is planned and run on its
-// own, and two limbs it is when none of the sampled distances comes near the threshold -- whatever exceeds it would be
-// redone over the full matrix, at ten times the cost of a window.
 int malcs_diag_plan(malcs_batch *b, int nlw, const std::vector<uint32_t> &pairs, const std::vector<uint8_t> &retry_class,
                     const std::vector<diag_retry> &classes)
 {
-    bool half_mode = false;
-    if (nlw == 3 && b->n_planes == 2 && !pairs.empty()) {
-        const char *env = getenv("MALCS_DIAG_HALF");
-        if (env && *env) {
-            half_mode = atoi(env) != 0;
-        } else if (pairs.size() >= 4096) {
-            malcs_stage_trace trace("window plan");
-            const size_t stride = pairs.size() / 1024;
-            std::vector<uint32_t> sample;
-            std::vector<uint8_t> sample_class;
-            for (size_t i = stride / 2; i < pairs.size(); i += stride) { sample.push_back(pairs[i]); sample_class.push_back(retry_class[i]); }
-            int rc = plan_window(b, nlw, sample, sample_class, classes, false);
-            if (rc) return rc;
-            hipStream_t st = b->ctx->stream;
-            std::vector<int32_t> dist(b->n_pairs);
-            MALCS_HIP(hipMemsetAsync(b->d_dist, 0xff, b->n_pairs * sizeof(int32_t), st));      // -1: the window did not settle the pair
-            rc = malcs_diag_launch(b, true);
-            if (rc) return rc;
-            MALCS_HIP(malcs_d2h(st, dist.data(), b->d_dist, b->n_pairs * sizeof(int32_t)));
-            MALCS_HIP(malcs_sync(st));
-            malcs_diag_release(b);
-            int32_t worst = 0;
-            for (uint32_t pid : sample) worst = std::max(worst, dist[pid] < 0 ? 0x7fffffff : dist[pid]);
-            half_mode = worst <= MALCS_DIAG_HALF_T - 6;
-            trace.lap(half_mode ? "sample: two limbs" : "sample: three limbs");
-        }
-    }
-    return plan_window(b, nlw, pairs, retry_class, classes, half_mode);
+    return plan_window(b, nlw, pairs, retry_class, classes);
 }
 
 // Launches the window kernel.  The retry counters exist twice: a launch appends through one set and zeroes
 // the other one for its successor (stream order makes that safe), which saves a memset per launch.
-// `advance` = false re-uses the current set without resetting it (timing loops over this kernel alone:
-// appends beyond a list's capacity are dropped by the kernel).
+// `advance` = false re-uses the current set without resetting it.
 int malcs_diag_launch(malcs_batch *b, bool advance)
 {
     diag_plan &d = b->diag;
@@ -880,8 +1064,8 @@ int malcs_diag_launch(malcs_batch *b, bool advance)
     if (ncls > 64) { malcs_set_error("too many retry classes"); return MALCS_ERR_INTERNAL; }
     if (advance) d.parity ^= 1u;
     uint32_t *cur = d.d_retry_count + d.parity * ncls, *next = d.d_retry_count + (d.parity ^ 1u) * ncls;
-    hipLaunchKernelGGL(fn, dim3(d.n_tiles), dim3(64), 0, st, d.d_rows, d.d_tile_off, d.d_tile_iters, b->d_dist,
-                       d.d_retry_list, d.d_retry_first, d.d_retry_cap, cur, next, advance ? ncls : 0u);
+    hipLaunchKernelGGL(fn, dim3(d.n_pieces), dim3(64), 0, st, d.d_rows, d.d_piece_off, d.d_piece_info, d.d_piece_join, b->d_dist,
+                       d.d_retry_list, d.d_retry_first, d.d_retry_cap, cur, next, advance ? ncls : 0u, d.d_join_buf, d.d_join_flag);
     MALCS_HIP(hipGetLastError());
     return MALCS_OK;
 }

@@ -60,6 +60,32 @@ struct malcs_ctx {
     size_t stage_cap = 0, stage_used = 0;
     std::vector<staged_copy> staged;
     uint32_t *noalloc_scratch = nullptr;   // this device's copy of the file-scope scratch array of malcs_noalloc.hip
+    // Device blocks that batches of this context have released, kept for the next batch: a hipMalloc costs a fraction
+    // of a millisecond and hipFree synchronises the device, which is most of what a small batch would otherwise pay.
+    struct pool_block { void *p; size_t bytes; bool used; };
+    std::vector<pool_block> pool;
+    size_t pool_bytes = 0;
+    // pinned host buffer for input that is packed on the host (malcs_batch_create): grows to the largest batch seen
+    char *pack_stage = nullptr;
+    size_t pack_stage_cap = 0;
+};
+
+// Pooled device memory of a context (the context's device must be current).  malcs_pool_free never synchronises: the
+// block may still be read by work queued on the context's stream, and is only handed out again to work queued later
+// on that same stream.
+hipError_t malcs_pool_alloc(malcs_ctx *c, void **p, size_t bytes);
+void malcs_pool_free(malcs_ctx *c, void *p);
+void malcs_pool_trim(malcs_ctx *c);            // hipFree everything that is not in use
+
+// pooled device memory that is released on every return path of the function that holds it
+template <typename T> struct pool_scoped {
+    malcs_ctx *c;
+    T *p = nullptr;
+    explicit pool_scoped(malcs_ctx *ctx) : c(ctx) {}
+    pool_scoped(const pool_scoped &) = delete;
+    pool_scoped &operator=(const pool_scoped &) = delete;
+    hipError_t alloc(size_t count) { return malcs_pool_alloc(c, (void **)&p, count * sizeof(T)); }
+    ~pool_scoped() { if (p) malcs_pool_free(c, p); }
 };
 
 // Copies on a context's stream and the wait for them.  Small copies are staged through the context's pinned buffer:
@@ -88,9 +114,12 @@ struct diag_plan {
     int T = 0;                           // results <= T are exact
     uint32_t n_tiles = 0, n_pairs = 0, n_half_tiles = 0;   // n_half_tiles: tiles in two-limb mode (T = 48)
     uint64_t window_cells = 0;           // sum over the class of 32 * nlw * (text length)
-    uint32_t *d_rows = nullptr;          // tiles of 64 pairs, lane-interleaved rows of 64 dwords; the allocation the arrays below are parts of
-    uint32_t *d_tile_off = nullptr;      // first row of each tile
-    uint32_t *d_tile_iters = nullptr;    // column blocks of each tile
+    uint32_t n_pieces = 0, n_cut_tiles = 0;   // workgroups of a launch; tiles that run as two pieces (cut at a block boundary)
+    uint32_t *d_rows = nullptr;          // per piece, lane-interleaved rows of 64 dwords; the allocation the arrays below are parts of
+    uint32_t *d_piece_off = nullptr;     // first row of each piece
+    uint32_t *d_piece_info = nullptr;    // column blocks of each piece | mode flags
+    uint32_t *d_piece_join = nullptr;    // for the pieces of a cut tile: which slot of the join buffer they meet in
+    uint32_t *d_join_buf = nullptr, *d_join_flag = nullptr;
     uint32_t *d_retry_list = nullptr, *d_retry_first = nullptr, *d_retry_cap = nullptr, *d_retry_count = nullptr;
     std::vector<diag_retry> retry;
     uint32_t parity = 0;                 // which of the two sets of retry counters the last launch used

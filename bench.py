@@ -4,8 +4,9 @@
     python bench.py [--gpus N] [--steps K] [--warmup W] [--pairs P]
 
 One "step" is one pass of kernel family 1 over a batch of P = 100 000 pairs of ~1 kb windows with
-~2 % indels, the packed bit-plane arena already resident in HBM.  With N > 1 the
-driver starts one rank per GPU (torch.distributed.run); every rank owns its own batch of P pairs
+~2 % indels, the packed bit-plane arena already resident in HBM.  With N > 1 there is
+one rank per GPU: started by a launcher (torch.distributed.run sets RANK / WORLD_SIZE / MASTER_*) or, when there is
+none, by this script itself (N child processes, started before anything touches the GPU); every rank owns its own batch of P pairs
 (independent pairs, no data-path collective => weak scaling) and the job rate is all pairs of
 all ranks over the slowest rank's time.
 
@@ -171,6 +172,28 @@ def relation_matrix(ctx, gen, world, fence, all_max):
             "stages_ms_rank0": {k[8:]: round(v * 1e3 / reps, 2) for k, v in stats.items() if k.startswith("seconds_")}}
 
 
+def spawn_ranks(n):
+    """`python bench.py --gpus N` without a launcher: start N fresh rank processes (one per GPU) with the rendezvous in
+    their environment, before this process has touched the GPU, and wait for them.  Rank 0 prints the JSON line;
+    returns the worst exit code."""
+    import socket
+    import subprocess
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    children = []
+    for r in range(n):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n),
+                   MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+        children.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env))
+    worst = 0
+    for c in children:
+        rc = c.wait()
+        if rc != 0 and worst == 0:
+            worst = rc if rc > 0 else 128 - rc
+    return worst
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -184,10 +207,12 @@ def main():
     ap.add_argument("--share-device", action="store_true", help="rehearsal: all ranks use GPU 0")
     args = ap.parse_args()
 
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        raise SystemExit(spawn_ranks(args.gpus))               # no launcher around us: this process becomes one
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if world != args.gpus and world > 1:
+    if world != args.gpus:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
     os.environ.setdefault("MALCS_DEVICE", str(local_rank))
 

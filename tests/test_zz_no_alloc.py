@@ -2,7 +2,8 @@
 malcs_edit_distance_batch, through the C-ABI: two calls in a row on one GPU, the second with a smaller input
 (the file-scope scratch array keeps the first call's contents), bit-exact.
 
-torch only supplies the device buffers a caller of this entry point would already own."""
+The device buffers a caller of this entry point would already own come straight from the HIP runtime libmalcs itself
+is linked against (hipMalloc / hipMemcpy through ctypes): no second framework initialises the GPU in this process."""
 
 import ctypes
 
@@ -33,22 +34,45 @@ def _existing(native, ctx, data, n_symbols):
     return out
 
 
-def _noalloc(native, ctx, torch, data, n_symbols):
-    dev = torch.device("cuda", ctx.device)
-    t = [torch.from_numpy(x.view(np.int64) if x.dtype == np.uint64 else (x.view(np.int32) if x.dtype == np.uint32 else x)).to(dev)
-         for x in data]
-    out = torch.full((len(data[1]),), -7, dtype=torch.int32, device=dev)
-    torch.cuda.synchronize(dev)
-    p = [ctypes.c_void_p(x.data_ptr()) for x in t]
-    rc = native.lib.malcs_edit_distance_noalloc(ctx.handle, None, p[0], data[0].size, p[1], p[2], p[3], p[4], len(data[1]), n_symbols,
-                                                ctypes.c_void_p(out.data_ptr()))
-    native.check(rc)
-    ctx.sync()
-    return out.cpu().numpy()
+_hip = None
+
+
+def _runtime():
+    global _hip
+    if _hip is None:
+        from algebra_amd import _native  # noqa: F401  (loads libmalcs and with it the HIP runtime; the soname then resolves to that copy)
+        _hip = ctypes.CDLL("libamdhip64.so.7")
+        _hip.hipMalloc.argtypes = [ctypes.POINTER(ctypes.c_void_p), ctypes.c_size_t]
+        _hip.hipMemcpy.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_size_t, ctypes.c_int]
+        _hip.hipFree.argtypes = [ctypes.c_void_p]
+    return _hip
+
+
+def _to_device(array):
+    hip = _runtime()
+    p = ctypes.c_void_p()
+    assert hip.hipMalloc(ctypes.byref(p), max(array.nbytes, 4)) == 0
+    assert hip.hipMemcpy(p, array.ctypes.data_as(ctypes.c_void_p), array.nbytes, 1) == 0      # hipMemcpyHostToDevice
+    return p
+
+
+def _noalloc(native, ctx, data, n_symbols):
+    hip = _runtime()
+    p = [_to_device(np.ascontiguousarray(x)) for x in data]
+    out = np.full(len(data[1]), -7, np.int32)
+    d_out = _to_device(out)
+    try:
+        native.check(native.lib.malcs_edit_distance_noalloc(ctx.handle, None, p[0], data[0].size, p[1], p[2], p[3], p[4], len(data[1]),
+                                                            n_symbols, d_out))
+        ctx.sync()
+        assert hip.hipMemcpy(out.ctypes.data_as(ctypes.c_void_p), d_out, out.nbytes, 2) == 0   # hipMemcpyDeviceToHost
+    finally:
+        for q in p + [d_out]:
+            hip.hipFree(q)
+    return out
 
 
 def test_noalloc_matches_existing_entry_two_calls():
-    import torch
     from algebra_amd import _native as native
     ctx = native.default_context()
     rs = np.random.RandomState(77)
@@ -57,19 +81,18 @@ def test_noalloc_matches_existing_entry_two_calls():
     lengths += list(rs.randint(0, 3000, 4000))
     big = _pairs(rs, lengths, 4)
     want = _existing(native, ctx, big, 4)
-    got = _noalloc(native, ctx, torch, big, 4)
+    got = _noalloc(native, ctx, big, 4)
     assert np.array_equal(got, want)
     # second call, smaller, other alphabet (three planes): the scratch array still holds the first call's lists
     small = _pairs(rs, list(rs.randint(0, 700, 300)) + [5000, 0, 33], 7, indel=0.1)
     want = _existing(native, ctx, small, 8)
-    got = _noalloc(native, ctx, torch, small, 8)
+    got = _noalloc(native, ctx, small, 8)
     assert np.array_equal(got, want)
     # and the first again: same answers as before
-    assert np.array_equal(_noalloc(native, ctx, torch, big, 4), _existing(native, ctx, big, 4))
+    assert np.array_equal(_noalloc(native, ctx, big, 4), _existing(native, ctx, big, 4))
 
 
 def test_noalloc_limits():
-    import torch
     from algebra_amd import _native as native
     ctx = native.default_context()
     rs = np.random.RandomState(78)
@@ -83,5 +106,5 @@ def test_noalloc_limits():
     want = _existing(native, ctx, tuple(data), 4)
     data[3] = data[3].copy()
     data[3][2] = np.uint64(data[0].size)                       # pair 2: b starts at the end of the buffer and has symbols
-    got = _noalloc(native, ctx, torch, tuple(data), 4)
+    got = _noalloc(native, ctx, tuple(data), 4)
     assert got[0] == want[0] and got[1] == -1 and got[2] == -1

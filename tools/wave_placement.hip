@@ -42,6 +42,13 @@ int main(int argc, char **argv)
         for (auto &kv : simd) hist[kv.second.size() < 7 ? kv.second.size() : 7]++;
         printf("launch %d: %d waves on %zu SIMDs; SIMDs with 1 / 2 / 3 / 4+ waves: %d / %d / %d / %d\n", rep, waves, simd.size(),
                hist[1], hist[2], hist[3], hist[4] + hist[5] + hist[6] + hist[7]);
+        {
+            // does workgroup w share its SIMD exactly with the workgroups w' = w (mod #SIMDs)?
+            int same = 0, total = 0;
+            const int S = (int)simd.size();
+            for (auto &kv : simd) { total++; bool ok = true; for (int i : kv.second) ok = ok && (i % S == kv.second[0] % S); same += ok; }
+            printf("  SIMDs whose workgroups all agree mod %d: %d of %d\n", S, same, total);
+        }
         if (rep == 2) {
             int shown = 0;
             std::map<int, int> gap;
