@@ -44,6 +44,7 @@ def _load():
         "malcs_batch_create": (c.c_int, [vp, vp, u64, vp, vp, vp, vp, u64, c.c_int, P(vp)]),
         "malcs_batch_destroy": (c.c_int, [vp]),
         "malcs_batch_size": (u64, [vp]),
+        "malcs_batch_replan": (c.c_int, [vp]),
         "malcs_edit_distance_launch": (c.c_int, [vp]),
         "malcs_edit_distance_fetch": (c.c_int, [vp, vp]),
         "malcs_edit_distance_time": (c.c_int, [vp, c.c_int, P(c.c_float)]),
@@ -179,6 +180,9 @@ class Batch:
             self.close()
         except Exception:
             pass
+
+    def replan(self):
+        check(lib.malcs_batch_replan(self.handle))
 
     def launch_distances(self):
         check(lib.malcs_edit_distance_launch(self.handle))

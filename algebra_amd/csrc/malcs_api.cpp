@@ -1,5 +1,8 @@
 // malcs_api.cpp -- the C-ABI of libmalcs (include/malcs.h): contexts, batches, family-1 entry points.
 #include "malcs_internal.hpp"
+#include "malcs_hostpack.hpp"
+#include <algorithm>
+#include <thread>
 #include <mutex>
 #include <cstdarg>
 #include <cstring>
@@ -241,9 +244,26 @@ static void batch_release(malcs_batch *b)
     if (!b) return;
     hipSetDevice(b->ctx->device);
     malcs_diag_release(b);
-    hipFree(b->d_planes); hipFree(b->d_a_off); hipFree(b->d_a_len); hipFree(b->d_b_off); hipFree(b->d_b_len);
-    hipFree(b->d_order); hipFree(b->d_dist);
+    malcs_pool_free(b->ctx, b->d_planes);
+    malcs_pool_free(b->ctx, b->d_pair_block);        // d_a_off ... d_order, d_dist are parts of it
     delete b;
+}
+
+// Do the 2 n sequences of a batch lie apart in the symbol buffer?  Then none is shared and every one gets its own place
+// in the arena without looking anything up.  Recognises the two usual layouts in one pass: a_0 b_0 a_1 b_1 ... and all
+// a_i followed by all b_i (or the other way round), each in ascending order.
+static bool sequences_apart(const uint64_t *a_off, const uint32_t *a_len, const uint64_t *b_off, const uint32_t *b_len, uint64_t n)
+{
+    bool interleaved = true, blocks = true;
+    uint64_t end = 0, a_end = 0, b_end = 0, a_min = ~0ull, b_min = ~0ull;
+    for (uint64_t i = 0; i < n && (interleaved || blocks); i++) {
+        interleaved = interleaved && a_off[i] >= end && b_off[i] >= a_off[i] + a_len[i];
+        end = b_off[i] + b_len[i];
+        blocks = blocks && a_off[i] >= a_end && b_off[i] >= b_end;
+        a_end = a_off[i] + a_len[i]; b_end = b_off[i] + b_len[i];
+        a_min = std::min(a_min, a_off[i]); b_min = std::min(b_min, b_off[i]);
+    }
+    return interleaved || (blocks && (a_end <= b_min || b_end <= a_min));
 }
 
 static int batch_build(malcs_ctx *ctx, const uint8_t *syms, uint64_t n_syms,
@@ -256,77 +276,128 @@ static int batch_build(malcs_ctx *ctx, const uint8_t *syms, uint64_t n_syms,
     b->n_planes = planes_for(n_symbols);
     const uint32_t NP = (uint32_t)b->n_planes;
 
-    // distinct sequences (pairs may share them: a relation-matrix tile re-uses every window many times)
-    // open addressing over (offset, length); the table holds sequence ids, empty slots are ~0
-    size_t table_size = 16;
-    while (table_size < (size_t)n_pairs * 4 + 4) table_size <<= 1;
-    std::vector<uint32_t> table(table_size, 0xffffffffu);
+    // ---- where every sequence goes in the arena ----------------------------------------------------------
     std::vector<uint64_t> seq_byte_off;
     std::vector<uint32_t> seq_len, seq_blk_off;
-    seq_byte_off.reserve((size_t)n_pairs * 2); seq_len.reserve((size_t)n_pairs * 2); seq_blk_off.reserve((size_t)n_pairs * 2);
     uint64_t total_blocks = 0;
-    auto intern = [&](uint64_t off, uint32_t len, uint32_t *id) -> int {
-        if (off > n_syms || (uint64_t)len > n_syms - off) { malcs_set_error("sequence [%llu,+%u) outside the symbol buffer of %llu bytes", (unsigned long long)off, len, (unsigned long long)n_syms); return MALCS_ERR_ARG; }
-        size_t slot = (size_t)((off * 0x9e3779b97f4a7c15ull) ^ ((uint64_t)len * 0xc2b2ae3d27d4eb4full)) >> 20 & (table_size - 1);
-        for (; table[slot] != 0xffffffffu; slot = (slot + 1) & (table_size - 1)) {
-            const uint32_t have = table[slot];
-            if (seq_byte_off[have] == off && seq_len[have] == len) { *id = have; return MALCS_OK; }
-        }
-        table[slot] = (uint32_t)seq_len.size();
-        *id = (uint32_t)seq_len.size();
-        seq_byte_off.push_back(off);
-        seq_len.push_back(len);
-        seq_blk_off.push_back((uint32_t)total_blocks);
-        total_blocks += (len + 31u) / 32u;
-        return MALCS_OK;
-    };
     b->a_off.resize(n_pairs); b->a_len.resize(n_pairs); b->b_off.resize(n_pairs); b->b_len.resize(n_pairs);
     b->max_len = 0;
-    for (uint64_t i = 0; i < n_pairs; i++) {
-        uint32_t ia, ib;
-        int rc = intern(a_off[i], a_len[i], &ia);
-        if (rc) return rc;
-        rc = intern(b_off[i], b_len[i], &ib);
-        if (rc) return rc;
-        if (total_blocks * NP >= 0xffffffffull) { malcs_set_error("batch needs more than 16 GiB of packed planes; split it"); return MALCS_ERR_TOO_LONG; }
-        b->a_off[i] = seq_blk_off[ia] * NP; b->a_len[i] = a_len[i];
-        b->b_off[i] = seq_blk_off[ib] * NP; b->b_len[i] = b_len[i];
-        if (a_len[i] > b->max_len) b->max_len = a_len[i];
-        if (b_len[i] > b->max_len) b->max_len = b_len[i];
+    {
+        uint64_t bad = 0;                                        // every sequence inside the symbol buffer?
+        for (uint64_t i = 0; i < n_pairs; i++)
+            bad |= (uint64_t)(a_off[i] > n_syms) | (uint64_t)((uint64_t)a_len[i] > n_syms - a_off[i]) |
+                   (uint64_t)(b_off[i] > n_syms) | (uint64_t)((uint64_t)b_len[i] > n_syms - b_off[i]);
+        if (bad) {
+            for (uint64_t i = 0; i < n_pairs; i++) {
+                const bool bad_a = a_off[i] > n_syms || (uint64_t)a_len[i] > n_syms - a_off[i];
+                const bool bad_b = b_off[i] > n_syms || (uint64_t)b_len[i] > n_syms - b_off[i];
+                if (!bad_a && !bad_b) continue;
+                malcs_set_error("sequence [%llu,+%u) outside the symbol buffer of %llu bytes", (unsigned long long)(bad_a ? a_off[i] : b_off[i]),
+                                bad_a ? a_len[i] : b_len[i], (unsigned long long)n_syms);
+                return MALCS_ERR_ARG;
+            }
+        }
+    }
+    if (sequences_apart(a_off, a_len, b_off, b_len, n_pairs)) {
+        seq_byte_off.resize((size_t)n_pairs * 2); seq_len.resize((size_t)n_pairs * 2); seq_blk_off.resize((size_t)n_pairs * 2);
+        for (uint64_t i = 0; i < n_pairs; i++) {
+            seq_byte_off[2 * i] = a_off[i]; seq_len[2 * i] = a_len[i]; seq_blk_off[2 * i] = (uint32_t)total_blocks;
+            b->a_off[i] = (uint32_t)total_blocks * NP; b->a_len[i] = a_len[i];
+            total_blocks += (a_len[i] + 31u) / 32u;
+            seq_byte_off[2 * i + 1] = b_off[i]; seq_len[2 * i + 1] = b_len[i]; seq_blk_off[2 * i + 1] = (uint32_t)total_blocks;
+            b->b_off[i] = (uint32_t)total_blocks * NP; b->b_len[i] = b_len[i];
+            total_blocks += (b_len[i] + 31u) / 32u;
+            b->max_len = std::max(b->max_len, std::max(a_len[i], b_len[i]));
+            if (total_blocks * NP >= 0xffffffffull) { malcs_set_error("batch needs more than 16 GiB of packed planes; split it"); return MALCS_ERR_TOO_LONG; }
+        }
+    } else {
+        // pairs share sequences (a relation-matrix tile re-uses every window many times): distinct ones only.
+        // Open addressing over (offset, length); the table holds sequence ids, empty slots are ~0.
+        size_t table_size = 16;
+        while (table_size < (size_t)n_pairs * 4 + 4) table_size <<= 1;
+        std::vector<uint32_t> table(table_size, 0xffffffffu);
+        seq_byte_off.reserve((size_t)n_pairs * 2); seq_len.reserve((size_t)n_pairs * 2); seq_blk_off.reserve((size_t)n_pairs * 2);
+        auto intern = [&](uint64_t off, uint32_t len) -> uint32_t {
+            size_t slot = (size_t)((off * 0x9e3779b97f4a7c15ull) ^ ((uint64_t)len * 0xc2b2ae3d27d4eb4full)) >> 20 & (table_size - 1);
+            for (; table[slot] != 0xffffffffu; slot = (slot + 1) & (table_size - 1)) {
+                const uint32_t have = table[slot];
+                if (seq_byte_off[have] == off && seq_len[have] == len) return have;
+            }
+            table[slot] = (uint32_t)seq_len.size();
+            seq_byte_off.push_back(off);
+            seq_len.push_back(len);
+            seq_blk_off.push_back((uint32_t)total_blocks);
+            total_blocks += (len + 31u) / 32u;
+            return (uint32_t)seq_len.size() - 1u;
+        };
+        for (uint64_t i = 0; i < n_pairs; i++) {
+            const uint32_t ia = intern(a_off[i], a_len[i]), ib = intern(b_off[i], b_len[i]);
+            if (total_blocks * NP >= 0xffffffffull) { malcs_set_error("batch needs more than 16 GiB of packed planes; split it"); return MALCS_ERR_TOO_LONG; }
+            b->a_off[i] = seq_blk_off[ia] * NP; b->a_len[i] = a_len[i];
+            b->b_off[i] = seq_blk_off[ib] * NP; b->b_len[i] = b_len[i];
+            b->max_len = std::max(b->max_len, std::max(a_len[i], b_len[i]));
+        }
     }
     const uint32_t n_seqs = (uint32_t)seq_len.size();
     b->arena_dwords = total_blocks * NP;
-    trace.lap("distinct sequences");
+    trace.lap("places in the arena");
 
     MALCS_HIP(hipSetDevice(ctx->device));
     hipStream_t st = ctx->stream;
-    dev_scoped<uint8_t> syms_dev; dev_scoped<uint64_t> sbo_dev; dev_scoped<uint32_t> sl_dev, sko_dev;   // staging of the pack kernel
-    uint8_t *&d_syms = syms_dev.p; uint64_t *&d_sbo = sbo_dev.p; uint32_t *&d_sl = sl_dev.p, *&d_sko = sko_dev.p;
     if (n_pairs) {
-        MALCS_HIP(hipMalloc(&b->d_planes, (b->arena_dwords + 4) * sizeof(uint32_t)));
-        MALCS_HIP(hipMalloc(&b->d_a_off, n_pairs * 4)); MALCS_HIP(hipMalloc(&b->d_a_len, n_pairs * 4));
-        MALCS_HIP(hipMalloc(&b->d_b_off, n_pairs * 4)); MALCS_HIP(hipMalloc(&b->d_b_len, n_pairs * 4));
-        MALCS_HIP(hipMalloc(&b->d_dist, n_pairs * 4));
+        // one block for everything per pair: a_off, a_len, b_off, b_len (copied below), order (malcs_dist_plan), dist
+        MALCS_HIP(malcs_pool_alloc(ctx, (void **)&b->d_planes, (b->arena_dwords + 4) * sizeof(uint32_t)));
+        const size_t np = ((size_t)n_pairs + 63) & ~(size_t)63;
+        MALCS_HIP(malcs_pool_alloc(ctx, (void **)&b->d_pair_block, 6 * np * sizeof(uint32_t)));
+        b->d_a_off = b->d_pair_block; b->d_a_len = b->d_pair_block + np; b->d_b_off = b->d_pair_block + 2 * np;
+        b->d_b_len = b->d_pair_block + 3 * np; b->d_order = b->d_pair_block + 4 * np;
+        b->d_dist = reinterpret_cast<int32_t *>(b->d_pair_block + 5 * np);
         MALCS_HIP(malcs_h2d(st, b->d_a_off, b->a_off.data(), n_pairs * 4));
         MALCS_HIP(malcs_h2d(st, b->d_a_len, b->a_len.data(), n_pairs * 4));
         MALCS_HIP(malcs_h2d(st, b->d_b_off, b->b_off.data(), n_pairs * 4));
         MALCS_HIP(malcs_h2d(st, b->d_b_len, b->b_len.data(), n_pairs * 4));
         if (total_blocks) {
-            MALCS_HIP(hipMalloc(&d_syms, n_syms ? n_syms : 1));
-            MALCS_HIP(hipMalloc(&d_sbo, (size_t)n_seqs * 8)); MALCS_HIP(hipMalloc(&d_sl, (size_t)n_seqs * 4)); MALCS_HIP(hipMalloc(&d_sko, (size_t)n_seqs * 4));
-            MALCS_HIP(malcs_h2d(st, d_syms, syms, n_syms));
-            MALCS_HIP(malcs_h2d(st, d_sbo, seq_byte_off.data(), (size_t)n_seqs * 8));
-            MALCS_HIP(malcs_h2d(st, d_sl, seq_len.data(), (size_t)n_seqs * 4));
-            MALCS_HIP(malcs_h2d(st, d_sko, seq_blk_off.data(), (size_t)n_seqs * 4));
-            int rc = malcs_pack_launch(ctx, d_syms, d_sbo, d_sl, d_sko, n_seqs, (uint32_t)total_blocks, b->n_planes, b->d_planes);
-            if (rc) return rc;
+            // the planes are packed here, on the host's cores, into pinned memory, and cross PCIe packed; every stretch
+            // the packers finish is queued for its copy at once
+            const size_t arena_bytes = (size_t)b->arena_dwords * sizeof(uint32_t);
+            if (ctx->pack_stage_cap < arena_bytes) {
+                MALCS_HIP(malcs_sync(st));                       // an earlier batch's copies may still read the old buffer
+                if (ctx->pack_stage) { (void)hipHostFree(ctx->pack_stage); ctx->pack_stage = nullptr; ctx->pack_stage_cap = 0; }
+                const size_t cap = arena_bytes + arena_bytes / 4 + (1u << 20);
+                if (hipHostMalloc((void **)&ctx->pack_stage, cap, hipHostMallocDefault) != hipSuccess) {
+                    (void)hipGetLastError();
+                    malcs_set_error("no pinned host memory for %zu bytes of packed planes", cap);
+                    return MALCS_ERR_NOMEM;
+                }
+                ctx->pack_stage_cap = cap;
+            }                                                    // (the buffer is idle: batch creation ends with the stream drained)
+            malcs_pack_job job{syms, seq_byte_off.data(), seq_len.data(), seq_blk_off.data(), n_seqs, b->n_planes,
+                               reinterpret_cast<uint32_t *>(ctx->pack_stage)};
+            hipError_t copy_error = hipSuccess;
+            uint32_t codes = 0;
+            int threads = 16;
+            if (const char *e = getenv("MALCS_PACK_THREADS")) threads = std::max(1, atoi(e));
+            threads = std::min<int>(threads, (int)std::max(1u, std::thread::hardware_concurrency()));
+            const int rc = malcs_host_pack(job, threads, [&](size_t first, size_t count) -> int {
+                copy_error = hipMemcpyAsync(b->d_planes + first, job.out + first, count * sizeof(uint32_t), hipMemcpyHostToDevice, st);
+                return copy_error == hipSuccess ? 0 : 1;
+            }, &codes);
+            if (rc) { malcs_set_error("copy of the packed planes failed: %s", hipGetErrorString(copy_error)); return MALCS_ERR_HIP; }
+            if (codes >> NP) {
+                malcs_set_error("symbol code %u and n_symbols = %d: the batch has codes beyond the %u bit planes n_symbols selects", codes, n_symbols, NP);
+                return MALCS_ERR_ARG;
+            }
+            if (n_symbols < (1 << NP) && codes >= (uint32_t)n_symbols) {
+                // the OR of all codes is an upper bound of every one; only when it is itself out of range can a code be
+                bool bad = false;
+                for (uint32_t s = 0; s < n_seqs && !bad; s++)
+                    for (uint32_t j = 0; j < seq_len[s]; j++) if (syms[seq_byte_off[s] + j] >= n_symbols) { bad = true; break; }
+                if (bad) { malcs_set_error("a symbol code is not below n_symbols = %d", n_symbols); return MALCS_ERR_ARG; }
+            }
         }
-        MALCS_HIP(malcs_sync(st));
     }
-    trace.lap("allocations, copies to the device, bit planes");
-    b->raw_syms = syms; b->raw_a_off = a_off; b->raw_b_off = b_off;
+    trace.lap("allocations, planes packed on the host, copies queued");
     const int rc = malcs_dist_plan(b);
-    b->raw_syms = nullptr; b->raw_a_off = b->raw_b_off = nullptr;
     trace.lap("distance plan");
     return rc;
 }
@@ -345,7 +416,11 @@ int malcs_batch_create(malcs_ctx *ctx, const uint8_t *syms, uint64_t n_syms,
     malcs_batch *b = new (std::nothrow) malcs_batch();
     if (!b) { malcs_set_error("out of host memory"); return MALCS_ERR_NOMEM; }
     int rc = batch_build(ctx, syms, n_syms, a_off, a_len, b_off, b_len, n_pairs, n_symbols, b);
-    if (rc) { batch_release(b); return rc; }
+    if (rc) {
+        (void)hipStreamSynchronize(ctx->stream);                 // copies out of the context's pinned buffers may be in flight
+        batch_release(b);
+        return rc;
+    }
     *out = b;
     return MALCS_OK;
 }
@@ -360,6 +435,13 @@ int malcs_batch_destroy(malcs_batch *b)
 }
 
 uint64_t malcs_batch_size(const malcs_batch *b) { return b ? b->n_pairs : 0; }
+
+int malcs_batch_replan(malcs_batch *b)
+{
+    if (!b) { malcs_set_error("batch is NULL"); return MALCS_ERR_ARG; }
+    MALCS_HIP(hipSetDevice(b->ctx->device));
+    return malcs_dist_plan(b);
+}
 
 int malcs_edit_distance_launch(malcs_batch *b)
 {

@@ -66,8 +66,13 @@ k_plan_ends(const uint32_t *__restrict__ planes, const uint32_t *__restrict__ a_
             const uint32_t *__restrict__ b_off, const uint32_t *__restrict__ b_len, const uint32_t *__restrict__ pairs,
             uint32_t count, uint32_t min_rows, int trim, uint32_t hist_stride, uint32_t *__restrict__ item, uint32_t *__restrict__ hist)
 {
+    // a hundred thousand pairs of seven different lengths: the workgroup counts in LDS first (2 * hist_stride bins,
+    // dynamic), then adds its non-empty bins to the histogram in memory
+    extern __shared__ uint32_t lds_hist[];
+    for (uint32_t k = threadIdx.x; k < 2u * hist_stride; k += blockDim.x) lds_hist[k] = 0u;
+    __syncthreads();
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= count) return;
+    if (i < count) {
     const uint32_t pid = pairs[i];
     const uint32_t la = a_len[pid], lb = b_len[pid];
     const bool a_short = la <= lb;
@@ -115,20 +120,34 @@ k_plan_ends(const uint32_t *__restrict__ planes, const uint32_t *__restrict__ a_
     item[IT_PO * count + i] = po; item[IT_TO * count + i] = to; item[IT_M * count + i] = m; item[IT_N * count + i] = n;
     item[IT_Q * count + i] = q; item[IT_MT * count + i] = mt; item[IT_NT * count + i] = nt;
     item[IT_DELTA * count + i] = delta; item[IT_ITERS * count + i] = iters;
-    atomicAdd(&hist[(delta > (uint32_t)MALCS_DIAG_HALF_T ? hist_stride : 0u) + iters], 1u);
+    atomicAdd(&lds_hist[(delta > (uint32_t)MALCS_DIAG_HALF_T ? hist_stride : 0u) + iters], 1u);
+    }
+    __syncthreads();
+    for (uint32_t k = threadIdx.x; k < 2u * hist_stride; k += blockDim.x) if (lds_hist[k]) atomicAdd(&hist[k], lds_hist[k]);
 }
 
 // Counting sort by (group, blocks): `cursor` starts as the host's exclusive scan of the histogram (in the order the
 // tiles are formed in); slot s of the sorted order gets the index of its item.  Pairs of equal key may land in any
 // order: they are interchangeable (same block count, same mode).
-__global__ void __launch_bounds__(256)
+__global__ void __launch_bounds__(1024)
 k_plan_scatter(const uint32_t *__restrict__ item, uint32_t count, uint32_t hist_stride, uint32_t *__restrict__ cursor,
                uint32_t *__restrict__ slot_item)
 {
+    // rank inside the workgroup from LDS counters, one reservation per non-empty key and workgroup from the cursors
+    extern __shared__ uint32_t lds_cnt[];                       // 2 * hist_stride counters, then as many bases
+    uint32_t *lds_base = lds_cnt + 2u * hist_stride;
+    for (uint32_t k = threadIdx.x; k < 2u * hist_stride; k += blockDim.x) lds_cnt[k] = 0u;
+    __syncthreads();
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= count) return;
-    const uint32_t key = (item[IT_DELTA * count + i] > (uint32_t)MALCS_DIAG_HALF_T ? hist_stride : 0u) + item[IT_ITERS * count + i];
-    slot_item[atomicAdd(&cursor[key], 1u)] = i;
+    uint32_t key = 0, rank = 0;
+    if (i < count) {
+        key = (item[IT_DELTA * count + i] > (uint32_t)MALCS_DIAG_HALF_T ? hist_stride : 0u) + item[IT_ITERS * count + i];
+        rank = atomicAdd(&lds_cnt[key], 1u);
+    }
+    __syncthreads();
+    for (uint32_t k = threadIdx.x; k < 2u * hist_stride; k += blockDim.x) if (lds_cnt[k]) lds_base[k] = atomicAdd(&cursor[k], lds_cnt[k]);
+    __syncthreads();
+    if (i < count) slot_item[lds_base[key] + rank] = i;
 }
 
 // piece_info: blocks of the piece | PIECE_* flags
@@ -181,39 +200,69 @@ k_diag_layout(const uint32_t *__restrict__ planes, const uint32_t *__restrict__ 
     const int kmax = delta + (Tm - delta) / 2;
     if (wave == 0) { out[0] = pairs[idx]; out[64] = m; out[128] = n; out[192] = (uint32_t)kmax | ((uint32_t)retry_class[idx] << 16); }
     out += META_ROWS * 64;
-    auto stored = [&](uint32_t base, int have, int wd, int p) -> uint32_t {    // word wd of a stored sequence, zero beyond its end
+    // Word wd (all planes) of a stored sequence, zero beyond its end or in front of it.
+    struct word { uint32_t p[NP]; };
+    auto stored = [&](uint32_t base, int have, int wd) -> word {
+        word w;
         const int valid = have - 32 * wd;
-        if (wd < 0 || valid <= 0) return 0u;
-        const uint32_t w = planes[base + (uint32_t)wd * NP + p];
-        return valid >= 32 ? w : (w & ((1u << valid) - 1u));
+        if (wd < 0 || valid <= 0) {
+#pragma unroll
+            for (int p = 0; p < NP; p++) w.p[p] = 0u;
+            return w;
+        }
+        const uint32_t keep = valid >= 32 ? ~0u : ((1u << valid) - 1u);
+        const uint32_t *src = planes + base + (uint32_t)wd * NP;
+        if constexpr (NP == 2) { const uint2 v = *reinterpret_cast<const uint2 *>(src); w.p[0] = v.x & keep; w.p[1] = v.y & keep; }
+        else if constexpr (NP == 4) { const uint4 v = *reinterpret_cast<const uint4 *>(src); w.p[0] = v.x & keep; w.p[1] = v.y & keep; w.p[2] = v.z & keep; w.p[3] = v.w & keep; }
+        else {
+#pragma unroll
+            for (int p = 0; p < NP; p++) w.p[p] = src[p] & keep;
+        }
+        return w;
     };
-    // 32 rows of the pattern from row rs (negative: above the matrix, those bits never matter) / the 32 columns of
-    // block blk of the text; both as cut, i.e. q symbols into the stored sequence
-    auto limb_fwd = [&](int rs, int p) -> uint32_t {
-        const int at = rs + (int)q, wd = at >> 5;                        // arithmetic shift = floor
-        const uint32_t sh = (uint32_t)at & 31u;
-        const uint32_t lo = stored(po, mt, wd, p);
-        return sh ? ((lo >> sh) | (stored(po, mt, wd + 1, p) << (32u - sh))) : lo;
-    };
-    auto text_fwd = [&](int blk, int p) -> uint32_t {
-        const uint32_t lo = stored(to, nt, blk, p);
-        return q ? ((lo >> q) | (stored(to, nt, blk + 1, p) << (32u - q))) : lo;
-    };
-    auto limb = [&](int rs, int p) -> uint32_t { return back ? __brev(limb_fwd((int)m - rs - 32, p)) : limb_fwd(rs, p); };
-    auto text = [&](int blk, int p) -> uint32_t { return back ? __brev(text_fwd((int)(n >> 5) - 1 - blk, p)) : text_fwd(blk, p); };
-    for (uint32_t r = wave; r < n_rows; r += 4) {
+    // Each wave writes a contiguous quarter of the piece's rows and walks its sequences word by word: a row needs the
+    // 32 symbols from some position `at` of the stored pattern (rows) / text (columns), i.e. words at >> 5 and the next
+    // one, and the next row needs the next words (the previous ones when the piece runs backwards).
+    //   forward:  pattern rows from 32 j - kmax for row j of the piece (j counts the start limbs too), text block it
+    //   backward: pattern rows from m - 32 - (32 j - kmax), bit-reversed; text block n / 32 - 1 - it, bit-reversed
+    const uint32_t per = (n_rows + 3u) / 4u, r0 = wave * per, r1 = min(n_rows, r0 + per);
+    if (r0 >= r1) return;
+    const int step = back ? -1 : 1;
+    // pattern: position of row j's first symbol in the stored sequence
+    auto pat_at = [&](int j) -> int { return (back ? (int)m - 32 - (32 * j - kmax) : 32 * j - kmax) + (int)q; };
+    int pw = pat_at((int)r0) >> 5;                                   // arithmetic shift = floor
+    const uint32_t psh = (uint32_t)pat_at((int)r0) & 31u;             // the same for every row: rows are 32 apart
+    word plo = stored(po, mt, pw), phi = stored(po, mt, pw + 1);
+    // text: block `it` of the piece = stored words tb, tb + 1 shifted by q
+    const int first_it = (int)r0 - (nlw - 1);                        // may be negative: the start limbs have no text
+    auto txt_blk = [&](int it) -> int { return back ? (int)(n >> 5) - 1 - it : it; };
+    int tw = txt_blk(first_it < 0 ? 0 : first_it);
+    word tlo = stored(to, nt, tw), thi = stored(to, nt, tw + 1);
+    for (uint32_t r = r0; r < r1; r++) {
+        uint32_t limb[NP];
+#pragma unroll
+        for (int p = 0; p < NP; p++) {
+            const uint32_t v = psh ? ((plo.p[p] >> psh) | (phi.p[p] << (32u - psh))) : plo.p[p];
+            limb[p] = back ? __brev(v) : v;
+        }
         if (r < (uint32_t)(nlw - 1)) {
 #pragma unroll
-            for (int p = 0; p < NP; p++) out[(r * NP + p) * 64u] = limb(32 * (int)r - kmax, p);
+            for (int p = 0; p < NP; p++) out[(r * NP + p) * 64u] = limb[p];
         } else {
             const int it = (int)r - (nlw - 1);
             uint32_t *o = out + (size_t)(nlw - 1) * NP * 64u + (size_t)it * 2u * NP * 64u;
 #pragma unroll
             for (int p = 0; p < NP; p++) {
-                o[p * 64u] = limb(32 * (it + nlw - 1) - kmax, p);
-                o[(NP + p) * 64u] = text(it, p);
+                const uint32_t v = q ? ((tlo.p[p] >> q) | (thi.p[p] << (32u - q))) : tlo.p[p];
+                o[p * 64u] = limb[p];
+                o[(NP + p) * 64u] = back ? __brev(v) : v;
             }
+            // the text moves on with the blocks only
+            tw += step;
+            if (back) { thi = tlo; tlo = stored(to, nt, tw); } else { tlo = thi; thi = stored(to, nt, tw + 1); }
         }
+        pw += step;
+        if (back) { phi = plo; plo = stored(po, mt, pw); } else { plo = phi; phi = stored(po, mt, pw + 1); }
     }
 }
 
@@ -846,29 +895,32 @@ static int plan_window(malcs_batch *b, int nlw, const std::vector<uint32_t> &pai
     MALCS_HIP(malcs_h2d(st, d_cls, retry_class.data(), count));
     MALCS_HIP(hipMemsetAsync(d_hist, 0, 2 * (size_t)HB * sizeof(uint32_t), st));
     const dim3 g256((count + 255u) / 256u), b256(256);
+    const size_t hist_lds = 2 * (size_t)HB * sizeof(uint32_t);
+    if (2 * hist_lds > 60000) { malcs_set_error("window plan: sequences of %u symbols are beyond its histogram", max_len); return MALCS_ERR_TOO_LONG; }
     switch (NP) {
-    case 2: hipLaunchKernelGGL(k_plan_ends<2>, g256, b256, 0, st, b->d_planes, b->d_a_off, b->d_a_len, b->d_b_off, b->d_b_len, d_pairs, count, min_rows, trim, HB, d_item, d_hist); break;
-    case 3: hipLaunchKernelGGL(k_plan_ends<3>, g256, b256, 0, st, b->d_planes, b->d_a_off, b->d_a_len, b->d_b_off, b->d_b_len, d_pairs, count, min_rows, trim, HB, d_item, d_hist); break;
-    case 4: hipLaunchKernelGGL(k_plan_ends<4>, g256, b256, 0, st, b->d_planes, b->d_a_off, b->d_a_len, b->d_b_off, b->d_b_len, d_pairs, count, min_rows, trim, HB, d_item, d_hist); break;
+    case 2: hipLaunchKernelGGL(k_plan_ends<2>, g256, b256, hist_lds, st, b->d_planes, b->d_a_off, b->d_a_len, b->d_b_off, b->d_b_len, d_pairs, count, min_rows, trim, HB, d_item, d_hist); break;
+    case 3: hipLaunchKernelGGL(k_plan_ends<3>, g256, b256, hist_lds, st, b->d_planes, b->d_a_off, b->d_a_len, b->d_b_off, b->d_b_len, d_pairs, count, min_rows, trim, HB, d_item, d_hist); break;
+    case 4: hipLaunchKernelGGL(k_plan_ends<4>, g256, b256, hist_lds, st, b->d_planes, b->d_a_off, b->d_a_len, b->d_b_off, b->d_b_len, d_pairs, count, min_rows, trim, HB, d_item, d_hist); break;
     }
     MALCS_HIP(hipGetLastError());
     std::vector<int32_t> sample_dist(sample.size(), 0);
     if (sampled) {
-        // the sampled pairs, grouped by their full-matrix class, through k_llcs_bitpar_list (exact distances into d_dist,
-        // where the real launch overwrites them later)
-        std::vector<uint32_t> list(sample.size()), first(classes.size() + 1, 0), fill(classes.size(), 0);
-        for (uint32_t i : sample) first[retry_class[i] + 1]++;
-        for (size_t c = 0; c < classes.size(); c++) first[c + 1] += first[c];
-        for (uint32_t i : sample) { const uint8_t c = retry_class[i]; list[first[c] + fill[c]++] = pairs[i]; }
+        // the sampled pairs through k_llcs_bitpar_list (exact distances into d_dist, where the real launch overwrites
+        // them later), all in ONE class: the fewest words per lane that 64 lanes per pair allow for the longest of
+        // them -- the sample is a few dozen waves, so its time is the time of one wave, and that is columns x limbs
+        uint32_t longest = 0;
+        std::vector<uint32_t> list(sample.size());
+        for (size_t k = 0; k < sample.size(); k++) { list[k] = pairs[sample[k]]; longest = std::max(longest, std::min(b->a_len[list[k]], b->b_len[list[k]])); }
+        const uint32_t words = std::max(1u, (longest + 63u) / 64u);
+        int W = 1, L = 1;
+        while ((uint32_t)W * 64u < words) W *= 2;
+        while ((uint32_t)(W * L) < words) L *= 2;
+        const uint32_t n_sample = (uint32_t)list.size(), ppw = 64u / (uint32_t)L;
         MALCS_HIP(malcs_h2d(st, d_sample, list.data(), list.size() * sizeof(uint32_t)));
-        MALCS_HIP(malcs_h2d(st, d_scount, fill.data(), fill.size() * sizeof(uint32_t)));
-        for (size_t c = 0; c < classes.size(); c++) {
-            if (!fill[c]) continue;
-            const uint32_t ppw = 64u / (uint32_t)classes[c].L;
-            const int rc = malcs_dist_launch_list(st, b->n_planes, classes[c].W, classes[c].L, b->d_planes, b->d_a_off, b->d_a_len, b->d_b_off,
-                                                  b->d_b_len, d_sample, first[c], d_scount + c, fill[c], (fill[c] + ppw - 1u) / ppw, b->d_dist);
-            if (rc) return rc;
-        }
+        MALCS_HIP(malcs_h2d(st, d_scount, &n_sample, sizeof(uint32_t)));
+        const int rc = malcs_dist_launch_list(st, b->n_planes, W, L, b->d_planes, b->d_a_off, b->d_a_len, b->d_b_off, b->d_b_len,
+                                              d_sample, 0, d_scount, n_sample, (n_sample + ppw - 1u) / ppw, b->d_dist);
+        if (rc) return rc;
         hipLaunchKernelGGL(k_plan_gather, dim3(((uint32_t)list.size() + 255u) / 256u), b256, 0, st, b->d_dist, d_sample, (uint32_t)list.size(),
                            reinterpret_cast<int32_t *>(d_sample + list.size()));
         MALCS_HIP(hipGetLastError());
@@ -1023,7 +1075,7 @@ static int plan_window(malcs_batch *b, int nlw, const std::vector<uint32_t> &pai
     MALCS_HIP(hipMemsetAsync(d.d_retry_count, 0, 2 * ncls * sizeof(uint32_t), st));
     MALCS_HIP(hipMemsetAsync(d.d_join_flag, 0, std::max(n_joins, 1u) * sizeof(uint32_t), st));
     MALCS_HIP(hipMemsetAsync(d_slot, 0xff, (size_t)n_tiles * 64u * sizeof(uint32_t), st));
-    hipLaunchKernelGGL(k_plan_scatter, g256, b256, 0, st, d_item, count, HB, d_hist, d_slot);
+    hipLaunchKernelGGL(k_plan_scatter, dim3((count + 1023u) / 1024u), dim3(1024), 2 * hist_lds, st, d_item, count, HB, d_hist, d_slot);
     switch (NP) {
     case 2: hipLaunchKernelGGL(k_diag_layout<2>, dim3(n_pieces), b256, 0, st, b->d_planes, d_item, count, d_pairs, d_cls, d_slot, d_tile_iters, d.d_piece_off, d.d_piece_info, d_piece_tile, nlw, T, d.d_rows); break;
     case 3: hipLaunchKernelGGL(k_diag_layout<3>, dim3(n_pieces), b256, 0, st, b->d_planes, d_item, count, d_pairs, d_cls, d_slot, d_tile_iters, d.d_piece_off, d.d_piece_info, d_piece_tile, nlw, T, d.d_rows); break;

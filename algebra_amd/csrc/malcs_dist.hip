@@ -387,64 +387,70 @@ int malcs_dist_launch_list(hipStream_t st, int n_planes, int W, int L, const uin
 int malcs_dist_plan(malcs_batch *b)
 {
     const uint64_t n = b->n_pairs;
+    malcs_stage_trace trace("distance plan");
     b->band_pairs.clear();
     const int wmax = max_words_per_lane(b->n_planes);
-    std::vector<uint8_t> cls(n);
-    // class id = index into table of (W, logL)
+    // class id = index into table of (W, logL); 255 = beyond a resident pattern, 254 = window class
     struct wl { int W, logL; };
     std::vector<wl> table;
-    auto class_of = [&](int W, int logL) -> int {
-        for (size_t i = 0; i < table.size(); i++) if (table[i].W == W && table[i].logL == logL) return (int)i;
+    auto class_of = [&](int W, int logL) -> uint8_t {
+        for (size_t i = 0; i < table.size(); i++) if (table[i].W == W && table[i].logL == logL) return (uint8_t)i;
         table.push_back({W, logL});
-        return (int)table.size() - 1;
+        return (uint8_t)(table.size() - 1);
     };
-    for (uint64_t i = 0; i < n; i++) {
-        uint32_t m = std::min(b->a_len[i], b->b_len[i]);
-        uint32_t words = std::max<uint32_t>(1u, (m + 63u) / 64u);
-        int W, logL = 0;
-        if (words <= 4 && (int)words <= wmax) {
-            W = (int)pow2ceil(words);
-        } else {
-            W = 4;
-            while ((uint32_t)W * 64u < words && W < wmax) W *= 2;
-            if ((uint32_t)W * 64u < words) {      // too long for a resident pattern: sliding-window kernel
-                b->band_pairs.push_back((uint32_t)i);
-                cls[i] = 255;
-                continue;
-            }
-            uint32_t lanes = pow2ceil((words + (uint32_t)W - 1u) / (uint32_t)W);
-            while ((1u << logL) < lanes) logL++;
-        }
-        cls[i] = (uint8_t)class_of(W, logL);
-    }
     // Window class (malcs_diag.hip): pairs long enough that a few limbs around the diagonal are much
     // less work than the whole matrix, and whose length difference alone does not already exceed what
-    // the window can prove.  Whatever it cannot settle returns to the class chosen above.
+    // the window can prove.  Whatever it cannot settle returns to the class chosen here.
     int nlw = 3;
     if (const char *e = getenv("MALCS_DIAG_NLW")) nlw = atoi(e);
-    std::vector<uint32_t> diag_pairs;
-    std::vector<uint8_t> diag_cls;
-    b->full_cells = 0;
-    for (uint64_t i = 0; i < n; i++) b->full_cells += (uint64_t)b->a_len[i] * b->b_len[i];
-    if (nlw > 0 && b->n_planes <= 4) {
-        const uint32_t T = (uint32_t)malcs_diag_threshold(nlw);
-        for (uint64_t i = 0; i < n; i++) {
-            if (cls[i] == 255) continue;
-            const uint32_t m = std::min(b->a_len[i], b->b_len[i]), mx = std::max(b->a_len[i], b->b_len[i]);
-            if ((m + 31u) / 32u >= 2u * (uint32_t)nlw + 2u && mx - m <= T) diag_pairs.push_back((uint32_t)i);
+    const bool window = nlw > 0 && b->n_planes <= 4;
+    const uint32_t T = window ? (uint32_t)malcs_diag_threshold(nlw) : 0u;
+    std::vector<uint8_t> cls(n), in_window(n, 0);
+    uint64_t cells = 0, n_window = 0;
+    uint32_t last_words = 0xffffffffu; uint8_t last_cls = 0;        // batches of equal lengths: one lookup
+    for (uint64_t i = 0; i < n; i++) {
+        const uint32_t la = b->a_len[i], lb = b->b_len[i];
+        const uint32_t m = std::min(la, lb), mx = std::max(la, lb);
+        cells += (uint64_t)la * lb;
+        const uint32_t words = std::max<uint32_t>(1u, (m + 63u) / 64u);
+        if (words != last_words) {
+            last_words = words;
+            int W, logL = 0;
+            if (words <= 4 && (int)words <= wmax) {
+                W = (int)pow2ceil(words);
+                last_cls = class_of(W, 0);
+            } else {
+                W = 4;
+                while ((uint32_t)W * 64u < words && W < wmax) W *= 2;
+                if ((uint32_t)W * 64u < words) {
+                    last_cls = 255;                    // too long for a resident pattern: sliding-window kernel
+                } else {
+                    const uint32_t lanes = pow2ceil((words + (uint32_t)W - 1u) / (uint32_t)W);
+                    while ((1u << logL) < lanes) logL++;
+                    last_cls = class_of(W, logL);
+                }
+            }
         }
-        if (diag_pairs.size() < 64) diag_pairs.clear();
+        cls[i] = last_cls;
+        if (last_cls == 255) { b->band_pairs.push_back((uint32_t)i); continue; }
+        if (window && (m + 31u) / 32u >= 2u * (uint32_t)nlw + 2u && mx - m <= T) { in_window[i] = 1; n_window++; }
     }
+    b->full_cells = cells;
     malcs_diag_release(b);
-    if (!diag_pairs.empty()) {
+    if (n_window >= 64) {
+        std::vector<uint32_t> diag_pairs(n_window);
+        std::vector<uint8_t> diag_cls(n_window);
         std::vector<int> retry_id(table.size(), -1);
         std::vector<diag_retry> classes;
-        for (uint32_t pid : diag_pairs) {
-            int &id = retry_id[cls[pid]];
-            if (id < 0) { id = (int)classes.size(); diag_retry r; r.W = table[cls[pid]].W; r.L = 1 << table[cls[pid]].logL; classes.push_back(r); }
-            diag_cls.push_back((uint8_t)id);
-            cls[pid] = 254;                        // not in the direct launches
+        size_t k = 0;
+        for (uint64_t i = 0; i < n; i++) {
+            if (!in_window[i]) continue;
+            int &id = retry_id[cls[i]];
+            if (id < 0) { id = (int)classes.size(); diag_retry r; r.W = table[cls[i]].W; r.L = 1 << table[cls[i]].logL; classes.push_back(r); }
+            diag_pairs[k] = (uint32_t)i; diag_cls[k] = (uint8_t)id; k++;
+            cls[i] = 254;                              // not in the direct launches
         }
+        trace.lap("classes");
         int rc = malcs_diag_plan(b, nlw, diag_pairs, diag_cls, classes);
         if (rc) return rc;
     }
@@ -452,19 +458,22 @@ int malcs_dist_plan(malcs_batch *b)
     std::vector<uint32_t> cnt(table.size() + 1, 0);
     for (uint64_t i = 0; i < n; i++) if (cls[i] < 254) cnt[cls[i] + 1]++;
     for (size_t c = 0; c < table.size(); c++) cnt[c + 1] += cnt[c];
-    std::vector<uint32_t> order(n), pos(cnt.begin(), cnt.end() - 1);
-    for (uint64_t i = 0; i < n; i++) if (cls[i] < 254) order[pos[cls[i]]++] = (uint32_t)i;
+    const uint32_t n_direct = cnt[table.size()];
     b->dist_buckets.clear();
     for (size_t c = 0; c < table.size(); c++) {
         dist_bucket k;
         k.W = table[c].W; k.L = 1 << table[c].logL; k.first = cnt[c]; k.count = cnt[c + 1] - cnt[c];
         if (k.count) b->dist_buckets.push_back(k);
     }
-    if (n) {
-        MALCS_HIP(hipMalloc(&b->d_order, n * sizeof(uint32_t)));
-        MALCS_HIP(malcs_h2d(b->ctx->stream, b->d_order, order.data(), n * sizeof(uint32_t)));
-        MALCS_HIP(malcs_sync(b->ctx->stream));   // `order` is a local
+    if (n_direct) {
+        std::vector<uint32_t> order(n_direct), pos(cnt.begin(), cnt.end() - 1);
+        for (uint64_t i = 0; i < n; i++) if (cls[i] < 254) order[pos[cls[i]]++] = (uint32_t)i;
+        MALCS_HIP(malcs_h2d(b->ctx->stream, b->d_order, order.data(), (size_t)n_direct * sizeof(uint32_t)));
+        MALCS_HIP(malcs_sync(b->ctx->stream));       // `order` is a local
+    } else if (n) {
+        MALCS_HIP(malcs_sync(b->ctx->stream));       // batch creation ends with the stream drained (the context's pinned buffers are idle again)
     }
+    trace.lap("direct classes");
     return MALCS_OK;
 }
 

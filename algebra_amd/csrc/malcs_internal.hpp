@@ -134,14 +134,12 @@ struct malcs_batch {
     uint32_t *d_a_off = nullptr, *d_a_len = nullptr, *d_b_off = nullptr, *d_b_len = nullptr;   // per pair (dword offsets)
     uint32_t *d_order = nullptr;         // pair ids grouped by bucket
     int32_t *d_dist = nullptr;
+    uint32_t *d_pair_block = nullptr;    // the allocation d_a_off ... d_dist are parts of
     // host mirrors
     std::vector<uint32_t> a_off, a_len, b_off, b_len;   // dword offsets into d_planes / lengths in symbols
     std::vector<dist_bucket> dist_buckets;
     std::vector<uint32_t> band_pairs;    // pairs too long for a resident pattern: sliding-window kernel
     diag_plan diag;
-    // the caller's buffers, valid only while malcs_batch_create runs (the plan looks for common ends of similar pairs)
-    const uint8_t *raw_syms = nullptr;
-    const uint64_t *raw_a_off = nullptr, *raw_b_off = nullptr;
     uint64_t full_cells = 0;             // sum of m * n over the batch
     uint64_t arena_dwords = 0;
     uint32_t max_len = 0;

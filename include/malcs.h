@@ -71,6 +71,10 @@ int malcs_batch_create(malcs_ctx *ctx, const uint8_t *syms, uint64_t n_syms,
                        uint64_t n_pairs, int n_symbols, malcs_batch **batch);
 int malcs_batch_destroy(malcs_batch *batch);
 uint64_t malcs_batch_size(const malcs_batch *batch);
+/* Runs the distance plan of a batch again, on the planes that are already resident: launch classes, and for the window
+ * class the common ends, the sort into tiles and the rows of every piece (all on the device).  The results of the
+ * batch do not change; bench.py times plan + launch with it, separately from the copy to the device. */
+int malcs_batch_replan(malcs_batch *batch);
 
 /* ---- kernel family 1: batched distances ---------------------------------------------------
  * Stands in for edit_distance(a, b) (algebra/lcs/edit_distance.py:21-53):

@@ -19,3 +19,12 @@ for rep in range(4):
     b.close()
     print(f"pairs={pairs} create={1e3 * (t1 - t0):.1f} ms distances={1e3 * (t2 - t1):.2f} ms "
           f"-> {pairs / (t2 - t0):.3e} pairs/s from host bytes ({data[0].nbytes / 1e6:.0f} MB), sum={int(d.sum())}", flush=True)
+b = N.Batch(ctx, *data, 4)
+for rep in range(3):
+    t0 = time.perf_counter()
+    for _ in range(10):
+        b.replan()
+        b.launch_distances()
+    ctx.sync()
+    t1 = time.perf_counter()
+    print(f"plan + launch on resident planes: {1e2 * (t1 - t0):.3f} ms per batch -> {pairs * 10 / (t1 - t0):.3e} pairs/s", flush=True)
