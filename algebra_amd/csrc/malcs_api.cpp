@@ -147,6 +147,8 @@ void malcs_pool_trim(malcs_ctx *c)
 // everything a context owns, released in reverse order of creation (also on the error paths of malcs_ctx_create)
 static void ctx_release(malcs_ctx *c)
 {
+    for (malcs_batch *b : c->spare_batches) delete b;
+    c->spare_batches.clear();
     malcs_pool_trim(c);
     if (c->pack_stage) hipHostFree(c->pack_stage);
     if (c->stage) hipHostFree(c->stage);
@@ -246,6 +248,15 @@ static void batch_release(malcs_batch *b)
     malcs_diag_release(b);
     malcs_pool_free(b->ctx, b->d_planes);
     malcs_pool_free(b->ctx, b->d_pair_block);        // d_a_off ... d_order, d_dist are parts of it
+    malcs_ctx *c = b->ctx;
+    if (c->spare_batches.size() < 2 && b->n_pairs <= (1u << 22)) {    // keep the object: its host arrays have their pages
+        b->d_planes = b->d_pair_block = b->d_a_off = b->d_a_len = b->d_b_off = b->d_b_len = b->d_order = nullptr;
+        b->d_dist = nullptr;
+        b->dist_buckets.clear(); b->band_pairs.clear();
+        b->n_pairs = 0; b->full_cells = 0; b->arena_dwords = 0; b->max_len = 0;
+        c->spare_batches.push_back(b);
+        return;
+    }
     delete b;
 }
 
@@ -277,8 +288,9 @@ static int batch_build(malcs_ctx *ctx, const uint8_t *syms, uint64_t n_syms,
     const uint32_t NP = (uint32_t)b->n_planes;
 
     // ---- where every sequence goes in the arena ----------------------------------------------------------
-    std::vector<uint64_t> seq_byte_off;
-    std::vector<uint32_t> seq_len, seq_blk_off;
+    std::vector<uint64_t> &seq_byte_off = ctx->seq_byte_off;
+    std::vector<uint32_t> &seq_len = ctx->seq_len, &seq_blk_off = ctx->seq_blk_off;
+    seq_byte_off.clear(); seq_len.clear(); seq_blk_off.clear();
     uint64_t total_blocks = 0;
     b->a_off.resize(n_pairs); b->a_len.resize(n_pairs); b->b_off.resize(n_pairs); b->b_len.resize(n_pairs);
     b->max_len = 0;
@@ -413,7 +425,9 @@ int malcs_batch_create(malcs_ctx *ctx, const uint8_t *syms, uint64_t n_syms,
     if (n_syms && !syms) { malcs_set_error("syms is NULL"); return MALCS_ERR_ARG; }
     if (n_symbols < 1 || n_symbols > 256) { malcs_set_error("n_symbols %d outside [1,256]", n_symbols); return MALCS_ERR_ARG; }
     if (n_pairs >= 0x7fffffffull) { malcs_set_error("too many pairs in one batch"); return MALCS_ERR_ARG; }
-    malcs_batch *b = new (std::nothrow) malcs_batch();
+    malcs_batch *b = nullptr;
+    if (!ctx->spare_batches.empty()) { b = ctx->spare_batches.back(); ctx->spare_batches.pop_back(); }
+    else b = new (std::nothrow) malcs_batch();
     if (!b) { malcs_set_error("out of host memory"); return MALCS_ERR_NOMEM; }
     int rc = batch_build(ctx, syms, n_syms, a_off, a_len, b_off, b_len, n_pairs, n_symbols, b);
     if (rc) {

@@ -137,8 +137,11 @@ int malcs_host_pack(const malcs_pack_job &job, int max_threads, const std::funct
     } catch (const std::system_error &) {}              // no more threads to be had: the ones we have do the rest
     int rc = 0;
     if (pool.empty()) work();                            // small input, or no threads: pack here, then ship
+    // finished chunks leave in order, a few megabytes at a time (a copy has a fixed cost of several microseconds)
+    const size_t ship_dwords = (4u << 20) / sizeof(uint32_t);
+    size_t pending_first = 0, pending_end = 0;
     for (size_t c = 0; c < n_chunks; c++) {
-        // with workers: this thread ships finished chunks, in order, and packs while it would otherwise wait
+        // with workers: this thread ships finished chunks and packs while it would otherwise wait
         while (!done[c].load(std::memory_order_acquire)) {
             const size_t mine = next_chunk.fetch_add(1, std::memory_order_relaxed);
             if (mine < n_chunks) {
@@ -150,10 +153,10 @@ int malcs_host_pack(const malcs_pack_job &job, int max_threads, const std::funct
                 std::this_thread::yield();
             }
         }
-        if (rc == 0) {
-            const size_t first = (size_t)job.seq_blk_off[cut[c]] * job.n_planes;
-            const size_t last = cut[c + 1] < n ? (size_t)job.seq_blk_off[cut[c + 1]] * job.n_planes : (size_t)total_blocks * job.n_planes;
-            if (last > first) rc = ship(first, last - first);
+        pending_end = cut[c + 1] < n ? (size_t)job.seq_blk_off[cut[c + 1]] * job.n_planes : (size_t)total_blocks * job.n_planes;
+        if (rc == 0 && (pending_end - pending_first >= ship_dwords || c + 1 == n_chunks) && pending_end > pending_first) {
+            rc = ship(pending_first, pending_end - pending_first);
+            pending_first = pending_end;
         }
     }
     for (std::thread &t : pool) t.join();

@@ -68,6 +68,11 @@ struct malcs_ctx {
     // pinned host buffer for input that is packed on the host (malcs_batch_create): grows to the largest batch seen
     char *pack_stage = nullptr;
     size_t pack_stage_cap = 0;
+    // host arrays of batch creation that are only needed while it runs, and batch objects that were destroyed: kept so
+    // that the next batch does not pay for fresh pages (a 100 000-pair batch touches 6 MB of them)
+    std::vector<uint64_t> seq_byte_off;
+    std::vector<uint32_t> seq_len, seq_blk_off;
+    std::vector<struct malcs_batch *> spare_batches;
 };
 
 // Pooled device memory of a context (the context's device must be current).  malcs_pool_free never synchronises: the

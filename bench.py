@@ -295,15 +295,46 @@ def main():
         algorithmic = f"{OPS_PER_CELL} lane-op/cell x {cells:.4g} cells/launch"
     achieved = kernel_cells * OPS_PER_CELL / (kernel_ms * 1e-3) / 1e12
 
+    # What a caller pays who computes a batch's distances once (rank 0's figures; every rank does the same work):
+    #   plan_inclusive  planes already resident in HBM: the whole plan (classes on the host; common ends, sort into tiles,
+    #                   rows of every piece on the device) + launch, per batch;
+    #   end_to_end      from the caller's host buffers (one byte per symbol, pageable numpy arrays) to distances in host
+    #                   memory: malcs_batch_create (planes packed on the host's cores, copied packed, plan) + launch +
+    #                   fetch + destroy.  PCIe-inclusive: never `value`.
+    reps = 20
+    batch.replan(); batch.launch_distances(); ctx.sync()
+    t0 = time.perf_counter()
+    for _ in range(reps):
+        batch.replan()
+        batch.launch_distances()
+    ctx.sync()
+    plan_s = (time.perf_counter() - t0) / reps
+    assert np.array_equal(batch.fetch_distances(), d)
+    for _ in range(2):
+        _native.Batch(ctx, syms, a_off, a_len, b_off, b_len, 4).close()
+    t0 = time.perf_counter()
+    for _ in range(reps):
+        once = _native.Batch(ctx, syms, a_off, a_len, b_off, b_len, 4)
+        d_once = once.distances()
+        once.close()
+    e2e_s = (time.perf_counter() - t0) / reps
+    assert np.array_equal(d_once, d)
+
     # the relation matrix is a job of all ranks (sharded tiles + all-gather): every rank takes part
     matrix = None if args.no_extra else relation_matrix(ctx, gen, world, fence, all_max)
 
     if rank == 0:
-        traffic = None                                       # HBM bytes per launch of that kernel, PMC passes of this command
-        pmc = os.path.join(ROOT, "profiles", "r01_pmc.json")
-        if os.path.exists(pmc) and args.pairs == 100000:
-            with open(pmc) as f:
-                traffic = json.load(f)["kernels"].get(kernel_name, {}).get("hbm_bytes_per_launch")
+        # HBM bytes per launch of that kernel: NOT measured in this run (counters need rocprofv3 passes of their own);
+        # read from the committed PMC summary of the same command and tagged with its source
+        traffic, traffic_source = None, None
+        for tag in ("r02", "r01"):
+            pmc = os.path.join(ROOT, "profiles", f"{tag}_pmc.json")
+            if os.path.exists(pmc) and args.pairs == 100000:
+                with open(pmc) as f:
+                    traffic = json.load(f)["kernels"].get(kernel_name, {}).get("hbm_bytes_per_launch")
+                if traffic is not None:
+                    traffic_source = f"profiles/{tag}_pmc.json"
+                    break
         out = {
             "metric": "GCUPS (batched LCS edit distance, 1 kb windows)",
             "value": round(total_cells * args.steps / elapsed / 1e9, 1),
@@ -319,9 +350,15 @@ def main():
             "mean_distance": round(mean_distance, 3),
             "roofline": {"bound": "valu", "achieved": round(achieved, 2), "peak": round(PEAK_LANE_OPS / 1e12, 1),
                          "unit": "T int32 lane-op/s", "frac": round(achieved * 1e12 / PEAK_LANE_OPS, 4),
-                         "traffic": traffic, "kernel": kernel_name, "kernel_ms": round(kernel_ms, 4),
+                         "traffic": traffic, "traffic_source": traffic_source, "kernel": kernel_name, "kernel_ms": round(kernel_ms, 4),
                          "step_ms_hip_events": round(step_ms, 4), "algorithmic": algorithmic},
             "plan": plan,
+            "plan_inclusive": {"pairs_per_s": round(args.pairs / plan_s, 1), "ms": round(plan_s * 1e3, 3),
+                               "what": "per batch, planes resident in HBM: distance plan (host classes; device: common ends, "
+                                       "sort into tiles, rows of every piece) + launch"},
+            "end_to_end": {"pairs_per_s": round(args.pairs / e2e_s, 1), "ms": round(e2e_s * 1e3, 3),
+                           "what": f"per batch, from {syms.nbytes / 1e6:.0f} MB of host bytes (pageable) to distances in host memory: "
+                                   "create (pack on host cores, copy packed, plan) + launch + fetch + destroy"},
         }
         if matrix is not None:
             out["relations_per_s"] = matrix["relations_per_s"]
@@ -330,6 +367,7 @@ def main():
             out["extra"].update(extra_configs(ctx, _native, gen))
         if world == 1 and not args.no_cpu_baseline:                # rank 0 at N = 1 only
             out["cpu_baseline"] = cpu_baseline(data, cells / args.pairs)
+            out["end_to_end"]["vs_cpu_port"] = round(out["end_to_end"]["pairs_per_s"] / out["cpu_baseline"]["pairs_per_s"], 2)
         print(json.dumps(out), flush=True)
 
     batch.close()
