@@ -55,6 +55,7 @@ def _load():
         "malcs_lcs_graph_batch": (c.c_int, [vp, vp, vp, P(vp)]),
         "malcs_lcs_nodes_batch": (c.c_int, [vp, vp, vp, P(vp)]),
         "malcs_graphs_destroy": (c.c_int, [vp]),
+        "malcs_graphs_from_runs": (c.c_int, [u64, vp, vp, vp, vp, vp, vp, P(vp)]),
         "malcs_graphs_counts": (c.c_int, [vp, vp]),
         "malcs_graphs_status": (c.c_int, [vp, vp, vp]),
         "malcs_graphs_supremal": (c.c_int, [vp, vp]),
@@ -285,6 +286,19 @@ class Graphs:
             self.close()
         except Exception:
             pass
+
+
+def graphs_from_runs(m, n, shift, n_levels, runs4, run_first):
+    """_build_graph on caller-provided level lists (host only): Graphs handle of len(m) pairs."""
+    m = np.ascontiguousarray(m, dtype=np.int64)
+    n = np.ascontiguousarray(n, dtype=np.int64)
+    shift = np.ascontiguousarray(shift, dtype=np.int64)
+    n_levels = np.ascontiguousarray(n_levels, dtype=np.int64)
+    runs4 = np.ascontiguousarray(runs4, dtype=np.int64).reshape(-1, 4)
+    run_first = np.ascontiguousarray(run_first, dtype=np.uint64)
+    handle = ctypes.c_void_p()
+    check(lib.malcs_graphs_from_runs(len(m), ptr(m), ptr(n), ptr(shift), ptr(n_levels), ptr(runs4), ptr(run_first), ctypes.byref(handle)))
+    return Graphs(handle, len(m))
 
 
 class RelationMatrix:

@@ -10,6 +10,7 @@
 //     trimming of source and sink :447-451, supremal :453.
 // The graph builder works on integer node ids and flat arrays; nothing here touches symbols.
 #include "malcs_internal.hpp"
+#include "malcs_graph_core.hpp"
 #include <algorithm>
 #include <atomic>
 #include <chrono>
@@ -141,185 +142,56 @@ bool runs_from_events(event_span ev, int64_t m, int64_t n, std::vector<run> &out
 }
 
 // ---- _build_graph -------------------------------------------------------------------------------
-struct gedge { int32_t child; int64_t start, end, from, to; };
-
-// Working state of one graph under construction.  A worker thread keeps one of these and clears it per pair: node
-// fields in flat arrays, the out-edges of all nodes as linked lists through one pool (append order = Node.edges
-// order), so that a batch of 100 000 small graphs costs no allocation per node.
+// The construction itself is malcs_graph_core.hpp (one source for this host path and for the device kernel of
+// malcs_gbuild.hip).  A worker thread keeps one arena and reuses it from pair to pair: no allocation per pair or node.
 struct builder {
-    // node arrays (Node.row/.col/.length/._length/._incoming, lcs_graph.py:36-44)
-    std::vector<int64_t> row, col, length, wlen, incoming;
-    std::vector<int32_t> head, tail;            // first / last pool entry of the node's edges, -1: none
-    std::vector<gedge> pool;
-    std::vector<int32_t> next;
-    std::vector<int32_t> cur, below, id, order;
-
-    void clear()
-    {
-        row.clear(); col.clear(); length.clear(); wlen.clear(); incoming.clear(); head.clear(); tail.clear();
-        pool.clear(); next.clear(); cur.clear(); below.clear(); id.clear(); order.clear();
-    }
-    int32_t add(int64_t r, int64_t c, int64_t l)
-    {
-        row.push_back(r); col.push_back(c); length.push_back(l); wlen.push_back(l); incoming.push_back(0);
-        head.push_back(-1); tail.push_back(-1);
-        return (int32_t)row.size() - 1;
-    }
-    bool no_edges(int32_t node) const { return head[node] < 0; }
-    void push(int32_t node, const gedge &e)
-    {
-        const int32_t slot = (int32_t)pool.size();
-        pool.push_back(e); next.push_back(-1);
-        if (tail[node] < 0) head[node] = slot; else next[tail[node]] = slot;
-        tail[node] = slot;
-    }
-    void copy_edges(int32_t dst, int32_t src)
-    {
-        for (int32_t i = head[src]; i >= 0; i = next[i]) { const gedge e = pool[i]; push(dst, e); }
-    }
+    std::vector<int32_t> mem, runs32;
+    int32_t node_cap = 0, edge_cap = 0, list_cap = 0;
 };
 
 void build_graph(builder &B, i64_store &store, int64_t m, int64_t n, int64_t shift, const std::vector<run> &runs, int64_t n_levels,
                  pair_graph &G)
 {
-    B.clear();
-    int32_t source, sink;
     const bool degenerate = runs.empty() || n_levels == 0;
     if (degenerate) {                                                    // :370-377
-        source = B.add(shift, shift, 0);
         if (m == 0 && n == 0) {
             G.supremal[0] = G.supremal[1] = G.supremal[2] = G.supremal[3] = 0;
+            G.nodes = store.take(3);
+            G.nodes[0] = shift; G.nodes[1] = shift; G.nodes[2] = 0;
+            G.edges = store.take(0);
         } else {
-            sink = B.add(m, n, 0);                                       // sink keeps unshifted coordinates
-            B.push(source, {sink, shift, shift + m, 0, n});
+            G.nodes = store.take(6);                                     // the sink keeps unshifted coordinates
+            G.nodes[0] = shift; G.nodes[1] = shift; G.nodes[2] = 0; G.nodes[3] = m; G.nodes[4] = n; G.nodes[5] = 0;
+            G.edges = store.take(6);
+            G.edges[0] = 0; G.edges[1] = 1; G.edges[2] = shift; G.edges[3] = shift + m; G.edges[4] = 0; G.edges[5] = n;
             G.supremal[0] = shift; G.supremal[1] = shift + m; G.supremal[2] = 0; G.supremal[3] = n;
         }
-    } else {
-        // Level lists: the runs arrive sorted by level, so level L is a contiguous range of node ids; only two
-        // lists are alive at a time (the level being emptied and the one below it), kept in two reused vectors
-        // -- the reference's list of ~LLCS lists would cost an allocation per level here.
-        for (const run &r : runs) B.add(r.row + shift, r.col + shift, r.len);      // node id == run index
-        size_t unread = runs.size();                                     // runs [0, unread) are not in a list yet
-        const int32_t last = (int32_t)runs.size() - 1;                   // last node of the last level, :379-385
-        if (B.row[last] + B.length[last] == m + shift && B.col[last] + B.length[last] == n + shift) {
-            unread--;                                                    // popped from its level
-            sink = B.add(B.row[last], B.col[last], B.length[last] + 1);
-        } else {
-            sink = B.add(m + shift, n + shift, 1);
-        }
-        std::vector<int32_t> &cur = B.cur, &below = B.below;
-        cur.push_back(sink);
-
-        int64_t max_sink = 0;
-        for (int64_t depth = n_levels + 1; depth > 1; depth--) {         // depth == len_lcs_nodes, :389
-            // Levels without runs of their own under a single live node only shorten that node by one each (no parent
-            // to meet, :418-423), under no node at all they do nothing: take them in one stride.  A 1 Mb window a
-            // few edits from its reference is almost nothing but such levels.
-            const int64_t idle = depth - 2 - (unread ? runs[unread - 1].level : -1);   // levels until the next run
-            if (idle > 0 && cur.size() <= 1) {
-                int64_t stride = idle;
-                if (cur.size() == 1) {
-                    const int32_t node = cur[0];
-                    if (node != sink && B.no_edges(node)) { cur.clear(); }
-                    else { stride = std::min<int64_t>(idle, B.wlen[node] - 1); B.wlen[node] -= stride; }
-                }
-                if (stride > 0) { depth -= stride - 1; continue; }
-            }
-            size_t first = unread;
-            while (first > 0 && runs[first - 1].level == depth - 2) first--;
-            below.clear();
-            for (size_t i = first; i < unread; i++) below.push_back((int32_t)i);
-            unread = first;
-            for (size_t qi = 0; qi < cur.size(); qi++) {                 // pop(0) in order, :390-391
-                const int32_t node = cur[qi];
-                if (node != sink && B.no_edges(node)) continue;          // :393-394
-                size_t idx_parent = 0;
-                const int64_t nr = B.row[node] + B.wlen[node], nc = B.col[node] + B.wlen[node];
-                for (size_t idx = 0; idx < below.size(); idx++) {        // :397
-                    const int32_t parent = below[idx];
-                    const int64_t pr = B.row[parent] + B.wlen[parent], pc = B.col[parent] + B.wlen[parent];
-                    if (pr < nr && pc < nc) {                            // :398 strict dominance of the ends
-                        const gedge e{node, pr, nr - 1, pc - shift, nc - 1 - shift};    // :399-400
-                        if (node == sink) max_sink = std::max(max_sink, nr - 1);         // :402-403
-                        if (B.incoming[parent] == depth) {               // :405-412 split the parent
-                            const int32_t split = B.add(B.row[parent], B.col[parent], B.length[parent]);
-                            B.wlen[split] = B.wlen[parent];
-                            B.copy_edges(split, parent);
-                            B.push(split, e);
-                            below[idx] = split;
-                            B.row[parent] += B.wlen[parent];
-                            B.col[parent] += B.wlen[parent];
-                            B.length[parent] -= B.wlen[parent];
-                        } else {
-                            B.push(parent, e);                           // :414
-                        }
-                        idx_parent = idx + 1;                            // :416
-                    }
-                }
-                if (B.wlen[node] > 1) {                                  // :418-423
-                    B.wlen[node] -= 1;
-                    if (idx_parent) B.incoming[node] = depth;
-                    below.insert(below.begin() + (std::ptrdiff_t)idx_parent, node);
-                }
-            }
-            cur.swap(below);                                             // :425
-        }
-
-        std::vector<int32_t> &l0 = cur;                                  // level 0, :428-432
-        size_t first = 0;
-        source = l0[0];
-        if (B.row[source] == shift && B.col[source] == shift) first = 1;
-        else source = B.add(shift, shift, 0);
-        for (size_t qi = first; qi < l0.size(); qi++) {                  // :434-445
-            const int32_t node = l0[qi];
-            if (node != sink && B.no_edges(node)) continue;
-            const int64_t nr = B.row[node] + B.wlen[node], nc = B.col[node] + B.wlen[node];
-            if (B.row[source] < nr && B.col[source] < nc) {
-                if (node == sink) max_sink = std::max(max_sink, nr - 1);
-                B.push(source, {node, B.row[source], nr - 1, B.col[source] - shift, nc - 1 - shift});
-            }
-        }
-        int64_t source_offset = shift;                                   // :447-451
-        if (!B.no_edges(source)) {
-            source_offset = B.pool[B.head[source]].start;
-            for (int32_t i = B.head[source]; i >= 0; i = B.next[i]) source_offset = std::min(source_offset, B.pool[i].start);
-        }
-        source_offset -= shift;
-        B.row[source] += source_offset;
-        B.col[source] += source_offset;
-        B.length[source] -= source_offset;
-        B.length[sink] -= B.row[sink] + B.length[sink] - max_sink;
-        G.supremal[0] = B.row[source];                                   // :453
-        G.supremal[1] = B.row[sink] + B.length[sink];
-        G.supremal[2] = B.col[source] - shift;
-        G.supremal[3] = B.col[sink] + B.length[sink] - shift;
+        return;
     }
-
-    // canonical numbering: BFS by identity from the source, following edge order
-    std::vector<int32_t> &id = B.id, &order = B.order;
-    id.assign(B.row.size(), -1);
-    id[source] = 0;
-    order.push_back(source);
-    size_t n_edges = 0;
-    for (size_t h = 0; h < order.size(); h++) {
-        for (int32_t i = B.head[order[h]]; i >= 0; i = B.next[i]) {
-            const int32_t child = B.pool[i].child;
-            if (id[child] < 0) { id[child] = (int32_t)order.size(); order.push_back(child); }
-            n_edges++;
-        }
+    const int32_t R = (int32_t)runs.size();
+    B.runs32.resize((size_t)R * 4);
+    for (int32_t r = 0; r < R; r++) {
+        B.runs32[4 * r] = (int32_t)runs[r].row; B.runs32[4 * r + 1] = (int32_t)runs[r].col;
+        B.runs32[4 * r + 2] = (int32_t)runs[r].len; B.runs32[4 * r + 3] = (int32_t)runs[r].level;
     }
-    G.nodes = store.take(order.size() * 3);
-    G.edges = store.take(n_edges * 6);
-    size_t ei = 0;
-    for (size_t h = 0; h < order.size(); h++) {
-        const int32_t u = order[h];
-        G.nodes[3 * h] = B.row[u]; G.nodes[3 * h + 1] = B.col[u]; G.nodes[3 * h + 2] = B.length[u];
-        for (int32_t i = B.head[u]; i >= 0; i = B.next[i]) {
-            const gedge &e = B.pool[i];
-            int64_t *o = &G.edges[6 * ei++];
-            o[0] = (int64_t)h; o[1] = id[e.child]; o[2] = e.start; o[3] = e.end; o[4] = e.from; o[5] = e.to;
-        }
+    int32_t node_cap = std::max(B.node_cap, 2 * R + 16), edge_cap = std::max(B.edge_cap, 4 * R + 64), list_cap = std::max(B.list_cap, R + 8);
+    malcs_core::arena A;
+    int32_t source = 0, sink = 0, sup[4] = {0, 0, 0, 0};
+    for (;;) {
+        B.mem.resize((size_t)malcs_core::arena_words(node_cap, edge_cap, list_cap));
+        malcs_core::arena_bind(A, B.mem.data(), node_cap, edge_cap, list_cap);
+        malcs_core::build(A, (int32_t)m, (int32_t)n, shift, B.runs32.data(), R, (int32_t)n_levels, source, sink, sup);
+        if (!A.overflow) break;
+        if (node_cap > (1 << 29) || edge_cap > (1 << 29)) throw std::bad_alloc();
+        node_cap *= 2; edge_cap *= 2; list_cap *= 2;                     // some array was too small: all of them grow
     }
+    B.node_cap = std::min(node_cap, 1 << 20); B.edge_cap = std::min(edge_cap, 1 << 22); B.list_cap = std::min(list_cap, 1 << 20);
+    int32_t n_edges = 0;
+    const int32_t count = malcs_core::number_nodes(A, source, n_edges);
+    G.nodes = store.take((size_t)count * 3);
+    G.edges = store.take((size_t)n_edges * 6);
+    malcs_core::write_graph<int64_t>(A, count, G.nodes.data(), G.edges.data(), shift);
+    G.supremal[0] = sup[0] + shift; G.supremal[1] = sup[1] + shift; G.supremal[2] = sup[2]; G.supremal[3] = sup[3];
 }
 
 // ---- canonical allele ---------------------------------------------------------------------------
@@ -841,6 +713,56 @@ int malcs_lcs_nodes_batch(malcs_batch *b, const int64_t *shift, const int64_t *m
     int rc;
     try {
         rc = nodes_batch(b, shift, max_distance, g);
+    } catch (const std::bad_alloc &) {
+        malcs_set_error("out of host memory");
+        rc = MALCS_ERR_NOMEM;
+    }
+    if (rc) { delete g; return rc; }
+    *graphs = g;
+    return MALCS_OK;
+}
+
+int malcs_graphs_from_runs(uint64_t n_pairs, const int64_t *m, const int64_t *n, const int64_t *shift, const int64_t *n_levels,
+                           const int64_t *runs4, const uint64_t *run_first, malcs_graphs **graphs)
+{
+    if (!graphs) { malcs_set_error("graphs is NULL"); return MALCS_ERR_ARG; }
+    *graphs = nullptr;
+    if (n_pairs && (!m || !n || !n_levels || !run_first)) { malcs_set_error("NULL argument"); return MALCS_ERR_ARG; }
+    malcs_graphs *g = new (std::nothrow) malcs_graphs();
+    if (!g) { malcs_set_error("out of host memory"); return MALCS_ERR_NOMEM; }
+    int rc = MALCS_OK;
+    try {
+        g->g.resize(n_pairs);
+        g->stores.resize(1);
+        builder B;
+        std::vector<run> runs;
+        for (uint64_t i = 0; i < n_pairs && rc == MALCS_OK; i++) {
+            pair_graph &G = g->g[i];
+            const int64_t sh = shift ? shift[i] : 0;
+            if (m[i] < 0 || n[i] < 0 || m[i] > 0x7ffffff0ll || n[i] > 0x7ffffff0ll || run_first[i + 1] < run_first[i]) {
+                malcs_set_error("pair %llu: bad lengths or run range", (unsigned long long)i); rc = MALCS_ERR_ARG; break;
+            }
+            runs.clear();
+            int64_t prev = -1;
+            for (uint64_t r = run_first[i]; r < run_first[i + 1]; r++) {
+                const int64_t *x = runs4 + 4 * r;                        // unshifted row, col; length; level
+                if (x[0] < 0 || x[1] < 0 || x[2] < 1 || x[0] + x[2] > m[i] || x[1] + x[2] > n[i] || x[3] < prev || x[3] >= n_levels[i]) {
+                    malcs_set_error("pair %llu: run %llu is outside the matrix or the levels are not ascending", (unsigned long long)i,
+                                    (unsigned long long)(r - run_first[i]));
+                    rc = MALCS_ERR_ARG; break;
+                }
+                prev = x[3];
+                runs.push_back({x[0], x[1], x[2], x[3]});
+            }
+            if (rc) break;
+            G.n_levels = n_levels[i];
+            G.distance = m[i] + n[i] - 2 * n_levels[i];                  // len(lcs_nodes) == LLCS whenever there are runs
+            G.runs = g->stores[0].take(runs.size() * 4);
+            for (size_t r = 0; r < runs.size(); r++) {
+                G.runs[4 * r] = runs[r].row + sh; G.runs[4 * r + 1] = runs[r].col + sh; G.runs[4 * r + 2] = runs[r].len; G.runs[4 * r + 3] = runs[r].level;
+            }
+            build_graph(B, g->stores[0], m[i], n[i], sh, runs, runs.empty() ? 0 : n_levels[i], G);
+        }
     } catch (const std::bad_alloc &) {
         malcs_set_error("out of host memory");
         rc = MALCS_ERR_NOMEM;

@@ -409,3 +409,19 @@ def _lcs_nodes(reference, observed, shift=0, max_distance=None):
         return int(res.distance[0]), levels
     finally:
         res.close()
+
+
+def _build_graph(reference, observed, lcs_nodes, shift=0):
+    """The compressed LCS graph from level lists of `LCSgraph.Node` (reference lcs_graph.py:351-453): returns
+    `(source, supremal)` as the reference does.  Runs in the host half of the library (`malcs_graphs_from_runs`, the
+    construction the batched entry points and the device kernel share); `lcs_nodes` is left as it was.
+    """
+    runs = [(node.row - shift, node.col - shift, node.length, level) for level, nodes in enumerate(lcs_nodes) for node in nodes]
+    n_levels = len(lcs_nodes) if runs else 0
+    res = _native.graphs_from_runs([len(reference)], [len(observed)], [shift], [n_levels],
+                                   np.array(runs, dtype=np.int64).reshape(-1, 4), [0, len(runs)])
+    try:
+        graph = LCSgraph._from_arrays(observed, res.distance[0], res.supremal[0], res.nodes(0), res.edges(0))
+    finally:
+        res.close()
+    return graph._source, graph.supremal

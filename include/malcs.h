@@ -159,6 +159,15 @@ int malcs_edit_distance_noalloc(malcs_ctx *ctx, void *stream, const uint8_t *d_s
 int malcs_lcs_graph_batch(malcs_batch *batch, const int64_t *shift, const int64_t *max_distance,
                           malcs_graphs **graphs);
 int malcs_graphs_destroy(malcs_graphs *graphs);
+/* Stands in for _build_graph(reference, observed, lcs_nodes, shift) (algebra/lcs/lcs_graph.py:351-453) called on its
+ * own, on level lists the caller already has (the reference's tests do that, tests/lcs/test_lcs_graph.py): host only,
+ * needs no device.  Pair i has sequences of m[i] / n[i] symbols and the runs run_first[i] .. run_first[i + 1] of
+ * runs4 = {row, col, length, level} (UNSHIFTED coordinates, in the order of the level lists, levels ascending);
+ * n_levels[i] = len(lcs_nodes).  The handle holds nodes, edges, supremal as malcs_lcs_graph_batch's does
+ * (distance = m + n - 2 * n_levels). */
+int malcs_graphs_from_runs(uint64_t n_pairs, const int64_t *m, const int64_t *n, const int64_t *shift,
+                           const int64_t *n_levels, const int64_t *runs4, const uint64_t *run_first,
+                           malcs_graphs **graphs);
 /* Stands in for _lcs_nodes(reference, observed, shift, max_distance) (algebra/lcs/lcs_graph.py:238-348) called on
  * its own: the distance and the level lists exactly as the reference's sweep fills them, i.e. with the runs it
  * walks over that lie on no minimal alignment as well (its tests pin them, tests/lcs/test_lcs_graph.py:20-51;
