@@ -65,6 +65,7 @@ def _load():
         "malcs_graphs_canonical_count": (c.c_int, [vp, u64, P(i64)]),
         "malcs_graphs_canonical": (c.c_int, [vp, u64, vp]),
         "malcs_graphs_timing": (c.c_int, [vp, vp]),
+        "malcs_graphs_device_built": (c.c_int, [vp, P(u64), P(c.c_float)]),
         "malcs_relmatrix_create": (c.c_int, [vp, u64, vp, vp, vp, vp, u32, u32, u32, P(vp)]),
         "malcs_relmatrix_destroy": (c.c_int, [vp]),
         "malcs_relmatrix_pending_count": (c.c_int, [vp, P(u64)]),
@@ -250,6 +251,9 @@ class Graphs:
                 check(lib.malcs_graphs_status(handle, ptr(self.status), ptr(self.distance)))
                 check(lib.malcs_graphs_supremal(handle, ptr(self.supremal)))
             check(lib.malcs_graphs_timing(handle, ptr(self.timing)))
+            built, ms = ctypes.c_uint64(), ctypes.c_float()
+            check(lib.malcs_graphs_device_built(handle, ctypes.byref(built), ctypes.byref(ms)))
+            self.device_built, self.device_build_ms = built.value, ms.value
         except Exception:
             self.close()
             raise

@@ -99,6 +99,44 @@ hipError_t malcs_sync(hipStream_t st)
     return c ? drain(c) : hipStreamSynchronize(st);
 }
 
+// ---- pinned host memory, process-wide ----------------------------------------------------------------
+namespace {
+struct pinned_block { void *p; size_t bytes; bool used; };
+std::mutex g_pinned_mutex;
+std::vector<pinned_block> g_pinned;
+}
+
+void *malcs_pinned_alloc(size_t bytes)
+{
+    bytes = (bytes + 4095u) & ~(size_t)4095u;
+    std::lock_guard<std::mutex> lock(g_pinned_mutex);
+    size_t best = (size_t)-1;
+    for (size_t i = 0; i < g_pinned.size(); i++) {
+        const pinned_block &k = g_pinned[i];
+        if (!k.used && k.bytes >= bytes && k.bytes <= 2 * bytes + (1u << 20) && (best == (size_t)-1 || k.bytes < g_pinned[best].bytes)) best = i;
+    }
+    if (best != (size_t)-1) { g_pinned[best].used = true; return g_pinned[best].p; }
+    // nothing fits: let go of what lies idle before asking for more (pinned memory is a scarce kind)
+    size_t idle = 0;
+    for (const pinned_block &k : g_pinned) if (!k.used) idle += k.bytes;
+    if (idle > (2ull << 30) || g_pinned.size() > 64) {
+        size_t kept = 0;
+        for (size_t i = 0; i < g_pinned.size(); i++) { if (g_pinned[i].used) g_pinned[kept++] = g_pinned[i]; else (void)hipHostFree(g_pinned[i].p); }
+        g_pinned.resize(kept);
+    }
+    void *p = nullptr;
+    if (hipHostMalloc(&p, bytes, hipHostMallocPortable) != hipSuccess) { (void)hipGetLastError(); return nullptr; }
+    g_pinned.push_back({p, bytes, true});
+    return p;
+}
+
+void malcs_pinned_free(void *p)
+{
+    if (!p) return;
+    std::lock_guard<std::mutex> lock(g_pinned_mutex);
+    for (pinned_block &k : g_pinned) if (k.p == p) { k.used = false; return; }
+}
+
 // ---- pooled device memory ---------------------------------------------------------------------------
 hipError_t malcs_pool_alloc(malcs_ctx *c, void **p, size_t bytes)
 {

@@ -34,7 +34,14 @@ int malcs_sweep_runs(malcs_batch *b, const std::vector<uint32_t> &work, const in
                      std::vector<uint32_t> &out_runs, std::vector<uint64_t> &out_first);
 
 int malcs_sweep_optimal_runs(malcs_batch *b, bool small, const std::vector<uint32_t> &work, int32_t *dist, int32_t unknown_cap,
-                             std::vector<uint32_t> &out_runs, std::vector<uint64_t> &out_first, float *ms);
+                             pinned_vec<uint32_t> &out_runs, std::vector<uint64_t> &out_first, float *ms,
+                             malcs_sweep_hook hook = nullptr, void *hook_user = nullptr);
+int malcs_gbuild_pair_out_words();
+int malcs_gbuild_launch(malcs_ctx *ctx, bool small, uint4 *d_runs, const uint64_t *d_run_off, const uint32_t *d_run_cnt,
+                        const uint32_t *d_pids, const uint32_t *d_slots, uint32_t n_slots, const uint32_t *d_a_len,
+                        const uint32_t *d_b_len, const int32_t *d_dist, const int64_t *d_shift, int32_t *d_scratch,
+                        const uint64_t *d_scratch_off, int32_t *d_out_words, uint64_t out_cap, unsigned long long *d_out_cursor,
+                        int32_t *d_pair_out);
 int malcs_sweep_small_dmax();
 
 namespace {
@@ -79,6 +86,15 @@ struct pair_graph {
     i64_view edges;                 // 6 per edge
     std::vector<int64_t> canon;     // 4 per canonical variant (start, end, obs_from, obs_to), filled on demand
     bool canon_done = false;
+    // a graph the device built (malcs_gbuild.hip): int32 words as they came home, coordinates without the shift;
+    // `nodes` / `edges` above are filled from them when somebody asks for the arrays (widen())
+    const int32_t *dev_nodes = nullptr, *dev_edges = nullptr;
+    const uint32_t *dev_runs = nullptr;      // its runs as the kernels left them (sorted, without the shift), 4 per run
+    int64_t dev_n_nodes = 0, dev_n_edges = 0, dev_n_runs = 0, dev_shift = 0;
+    bool dev_built = false;
+    size_t n_nodes() const { return dev_built ? (size_t)dev_n_nodes : nodes.size() / 3; }
+    size_t n_edges() const { return dev_built ? (size_t)dev_n_edges : edges.size() / 6; }
+    size_t n_runs() const { return dev_built ? (size_t)dev_n_runs : runs.size() / 4; }
 };
 
 // ---- events -> runs in the reference's emission order -------------------------------------------
@@ -320,11 +336,125 @@ double now_ms()
 
 }  // namespace
 
+// [0]: long windows (workgroup of 512), [1]: windows below 4 096 rows at small distance (a wave each),
+// [2], [3]: sequences beyond a resident pattern, whose sweeps also find the distance
+struct sweep_set { std::vector<uint32_t> pairs; pinned_vec<uint32_t> flat; std::vector<uint64_t> first; };
+
 struct malcs_graphs {
     std::vector<pair_graph> g;
+    sweep_set sweeps[4];
     std::deque<i64_store> stores;   // one per worker thread
-    float timing[3] = {0, 0, 0};
+    std::deque<pinned_vec<int32_t>> dev_words;    // graphs the device built, one buffer per chunk of pairs
+    float timing[4] = {0, 0, 0, 0};               // [3]: device graph construction (malcs_gbuild.hip)
+    uint64_t n_dev_built = 0;
 };
+
+// the int64 arrays of a graph the device built (rows, columns and variant positions get their shift here)
+static void widen(malcs_graphs *g, pair_graph &G)
+{
+    if (!G.dev_built || G.nodes.p) return;
+    if (g->stores.empty()) g->stores.resize(1);
+    G.runs = g->stores[0].take((size_t)G.dev_n_runs * 4);
+    for (int64_t r = 0; r < G.dev_n_runs; r++) {
+        G.runs[4 * r] = G.dev_runs[4 * r] + G.dev_shift; G.runs[4 * r + 1] = G.dev_runs[4 * r + 1] + G.dev_shift;
+        G.runs[4 * r + 2] = G.dev_runs[4 * r + 2]; G.runs[4 * r + 3] = G.dev_runs[4 * r + 3];
+    }
+    G.nodes = g->stores[0].take((size_t)G.dev_n_nodes * 3);
+    G.edges = g->stores[0].take((size_t)G.dev_n_edges * 6);
+    for (int64_t v = 0; v < G.dev_n_nodes; v++) {
+        G.nodes[3 * v] = G.dev_nodes[3 * v] + G.dev_shift; G.nodes[3 * v + 1] = G.dev_nodes[3 * v + 1] + G.dev_shift;
+        G.nodes[3 * v + 2] = G.dev_nodes[3 * v + 2];
+    }
+    for (int64_t e = 0; e < G.dev_n_edges; e++) {
+        const int32_t *x = G.dev_edges + 6 * e;
+        int64_t *o = &G.edges[6 * e];
+        o[0] = x[0]; o[1] = x[1]; o[2] = x[2] + G.dev_shift; o[3] = x[3] + G.dev_shift; o[4] = x[4]; o[5] = x[5];
+    }
+}
+
+// After the sweeps have compacted a chunk's runs on the device: order them and build the graphs there
+// (malcs_gbuild.hip), bring the finished node / edge arrays home.  Pairs the kernels give up stay as they are (their
+// runs, now sorted, come home with the others) and are built by the host half.
+struct gbuild_user {
+    malcs_batch *b; malcs_graphs *out; const int64_t *shift; const int64_t *d_shift;
+    const std::vector<uint32_t> *work;                                   // the work list the chunk's work_index refers to
+};
+
+static int gbuild_hook(void *user_, const malcs_sweep_chunk &c)
+{
+    gbuild_user &u = *static_cast<gbuild_user *>(user_);
+    malcs_stage_trace stages("graph kernels");
+    malcs_ctx *ctx = u.b->ctx;
+    hipStream_t st = ctx->stream;
+    const int PO = malcs_gbuild_pair_out_words();
+    std::vector<uint32_t> small, big;
+    std::vector<uint64_t> scratch_off(c.count, 0);
+    uint64_t scratch_words = 0, out_cap = 0;
+    for (uint32_t f = 0; f < c.count; f++) {
+        const uint32_t R = c.cnt[f], pid = c.pids[f];
+        if (R == 0 || u.b->a_len[pid] >= (1u << 30) || u.b->b_len[pid] >= (1u << 30)) continue;
+        if (R <= 64) small.push_back(f);
+        else if (R <= 1024) { big.push_back(f); scratch_off[f] = scratch_words; scratch_words += (uint64_t)malcs_core::arena_words(2 * (int32_t)R + 16, 8 * (int32_t)R + 64, (int32_t)R + 8); }
+        else continue;
+        out_cap += 3ull * (2ull * R + 8) + 6ull * (4ull * R + 16);      // more than graphs of R runs usually need; beyond it the host builds
+    }
+    if (small.empty() && big.empty()) return MALCS_OK;
+    const size_t n_slots = small.size() + big.size();
+    pool_scoped<uint32_t> d_slots(ctx);
+    pool_scoped<uint64_t> d_scratch_off(ctx);
+    pool_scoped<int32_t> d_scratch(ctx), d_words(ctx), d_pair_out(ctx);
+    pool_scoped<unsigned long long> d_cursor(ctx);
+    MALCS_HIP(d_slots.alloc(n_slots)); MALCS_HIP(d_scratch_off.alloc(c.count)); MALCS_HIP(d_scratch.alloc(std::max<uint64_t>(scratch_words, 1)));
+    MALCS_HIP(d_words.alloc(out_cap)); MALCS_HIP(d_pair_out.alloc((size_t)c.count * PO)); MALCS_HIP(d_cursor.alloc(1));
+    stages.lap("classes, allocations");
+    std::vector<uint32_t> slots(small);
+    slots.insert(slots.end(), big.begin(), big.end());
+    MALCS_HIP(malcs_h2d(st, d_slots.p, slots.data(), n_slots * sizeof(uint32_t)));
+    MALCS_HIP(malcs_h2d(st, d_scratch_off.p, scratch_off.data(), (size_t)c.count * sizeof(uint64_t)));
+    MALCS_HIP(hipMemsetAsync(d_cursor.p, 0, sizeof(unsigned long long), st));
+    MALCS_HIP(hipEventRecord(ctx->ev1, st));
+    int rc = malcs_gbuild_launch(ctx, true, c.d_runs, c.d_run_off, c.d_run_cnt, c.d_pids, d_slots.p, (uint32_t)small.size(), u.b->d_a_len, u.b->d_b_len,
+                                 u.b->d_dist, u.d_shift, d_scratch.p, d_scratch_off.p, d_words.p, out_cap, d_cursor.p, d_pair_out.p);
+    if (rc) return rc;
+    rc = malcs_gbuild_launch(ctx, false, c.d_runs, c.d_run_off, c.d_run_cnt, c.d_pids, d_slots.p + small.size(), (uint32_t)big.size(), u.b->d_a_len,
+                             u.b->d_b_len, u.b->d_dist, u.d_shift, d_scratch.p, d_scratch_off.p, d_words.p, out_cap, d_cursor.p, d_pair_out.p);
+    if (rc) return rc;
+    MALCS_HIP(hipEventRecord(ctx->ev2, st));
+    pinned_vec<int32_t> pair_out;
+    pair_out.resize((size_t)c.count * PO);
+    unsigned long long used = 0;
+    MALCS_HIP(hipMemcpyAsync(pair_out.data(), d_pair_out.p, pair_out.size() * sizeof(int32_t), hipMemcpyDeviceToHost, st));
+    MALCS_HIP(malcs_d2h(st, &used, d_cursor.p, sizeof(used)));
+    MALCS_HIP(malcs_sync(st));
+    float ms = 0;
+    MALCS_HIP(hipEventElapsedTime(&ms, ctx->ev1, ctx->ev2));
+    u.out->timing[3] += ms;
+    stages.lap("kernels, counts home");
+    used = std::min<unsigned long long>(used, out_cap);
+    u.out->dev_words.emplace_back();
+    pinned_vec<int32_t> &words = u.out->dev_words.back();
+    words.resize((size_t)used);
+    if (used) {
+        MALCS_HIP(hipMemcpyAsync(words.data(), d_words.p, (size_t)used * sizeof(int32_t), hipMemcpyDeviceToHost, st));
+        MALCS_HIP(malcs_sync(st));
+    }
+    stages.lap("graphs home");
+    for (uint32_t f : slots) {
+        const int32_t *po = pair_out.data() + (size_t)f * PO;
+        if (po[0] != 0) continue;                                         // given up: the host half builds this one
+        const uint64_t at = (uint64_t)(uint32_t)po[7] | ((uint64_t)(uint32_t)po[8] << 32);
+        const uint64_t n_nodes = (uint64_t)po[1], n_edges = (uint64_t)po[2];
+        if (at + 3 * n_nodes + 6 * n_edges > used) continue;
+        pair_graph &G = u.out->g[c.pids[f]];
+        const int64_t sh = u.shift ? u.shift[c.pids[f]] : 0;
+        G.dev_nodes = words.data() + at; G.dev_edges = words.data() + at + 3 * n_nodes;
+        G.dev_n_nodes = (int64_t)n_nodes; G.dev_n_edges = (int64_t)n_edges; G.dev_shift = sh;
+        G.supremal[0] = po[3] + sh; G.supremal[1] = po[4] + sh; G.supremal[2] = po[5]; G.supremal[3] = po[6];
+        G.dev_built = true;
+        u.out->n_dev_built++;
+    }
+    return MALCS_OK;
+}
 
 static int graph_batch(malcs_batch *b, const int64_t *shift, const int64_t *max_distance, malcs_graphs *out)
 {
@@ -339,8 +469,7 @@ static int graph_batch(malcs_batch *b, const int64_t *shift, const int64_t *max_
 
     // [0]: long windows (workgroup of 512), [1]: windows below 4 096 rows at small distance (a wave each),
     // [2], [3]: sequences beyond a resident pattern, whose sweeps also find the distance
-    struct sweep_set { std::vector<uint32_t> pairs, flat; std::vector<uint64_t> first; };
-    sweep_set sweeps[4];
+    sweep_set (&sweeps)[4] = out->sweeps;                // the handle keeps them: runs are read in place
     std::vector<uint64_t> sweep_slot(N, 0);
     int64_t sweep_dmax = 32768;                         // beyond: the table (D^2 / 2 words) and the single workgroup stop paying
     if (const char *e = getenv("MALCS_SWEEP_DMAX")) sweep_dmax = atoll(e);
@@ -453,11 +582,19 @@ static int graph_batch(malcs_batch *b, const int64_t *shift, const int64_t *max_
     const uint64_t budget_dwords = std::min<uint64_t>(free_b / 2, 64ull << 30) / 4;
 
     stages.lap("launch classes");
+    pool_scoped<int64_t> d_shift(ctx);                                   // the shifts, for the graph kernels (the trim of a sink no edge reaches needs them)
+    if (shift && N && (!sweeps[0].pairs.empty() || !sweeps[1].pairs.empty())) {
+        MALCS_HIP(d_shift.alloc(N));
+        MALCS_HIP(hipMemcpyAsync(d_shift.p, shift, N * sizeof(int64_t), hipMemcpyHostToDevice, st));
+        MALCS_HIP(malcs_sync(st));
+    }
     for (int shape = 0; shape < 2; shape++) {
         sweep_set &S = sweeps[shape];
         if (S.pairs.empty()) continue;
         float ms[2] = {0, 0};
-        int rc = malcs_sweep_optimal_runs(b, shape == 1, S.pairs, dist.data(), 0, S.flat, S.first, ms);
+        gbuild_user user{b, out, shift, d_shift.p, &S.pairs};
+        const bool on_device = !(getenv("MALCS_GBUILD") && atoi(getenv("MALCS_GBUILD")) == 0);      // MALCS_GBUILD=0: host half only
+        int rc = malcs_sweep_optimal_runs(b, shape == 1, S.pairs, dist.data(), 0, S.flat, S.first, ms, on_device ? gbuild_hook : nullptr, &user);
         if (rc) return rc;
         ms_fwd += ms[0]; ms_reach += ms[1];
         for (size_t s = 0; s < S.pairs.size(); s++) sweep_slot[S.pairs[s]] = s;
@@ -596,21 +733,33 @@ static int graph_batch(malcs_batch *b, const int64_t *shift, const int64_t *max_
         i64_store &store = *mine;
         std::vector<run> runs;
         builder B;
+        // pairs are taken in blocks: a block of small graphs costs about what the shared counter does, and a graph with
+        // hundreds of thousands of edges ends the block that holds it
+        const uint64_t block = N >= 4096 ? 64 : 1;
+        uint64_t i = 0, block_end = 0;
         for (;;) {
-            const uint64_t i = next.fetch_add(1);
+            if (++i >= block_end) { i = next.fetch_add(block); block_end = std::min<uint64_t>(N, i + block); }
             if (i >= N) break;
             pair_graph &G = out->g[i];
             if (G.status != MALCS_PAIR_OK) continue;
             const int64_t m = b->a_len[i], n = b->b_len[i];
+            if (G.dev_built) {                                           // all done on the device: point at what came home
+                const sweep_set &S = sweeps[has_runs[i] - 2];
+                const uint64_t s = sweep_slot[i];
+                G.dev_runs = S.flat.data() + 4 * S.first[s];
+                G.dev_n_runs = (int64_t)(S.first[s + 1] - S.first[s]);
+                G.n_levels = (m + n - G.distance) / 2;
+                continue;
+            }
             runs.clear();
             const double ta = trace ? now_ms() : 0;
             if (has_runs[i] >= 2) {                                      // runs straight from the sweep kernels
                 const uint64_t s = sweep_slot[i];
-                const std::vector<uint32_t> &flat = sweeps[has_runs[i] - 2].flat;
+                const pinned_vec<uint32_t> &flat = sweeps[has_runs[i] - 2].flat;
                 const std::vector<uint64_t> &first = sweeps[has_runs[i] - 2].first;
                 for (uint64_t r = first[s]; r < first[s + 1]; r++)
                     runs.push_back({flat[4 * r], flat[4 * r + 1], flat[4 * r + 2], flat[4 * r + 3]});
-                order_runs(runs, m, n);
+                if (!G.dev_built) order_runs(runs, m, n);                 // the graph kernels leave their runs in order
             } else if (has_runs[i] && !runs_from_events(pair_events[i], m, n, runs)) { failed.store(1); continue; }
             const double tb = trace ? now_ms() : 0;
             const int64_t llcs = (m + n - G.distance) / 2;
@@ -623,7 +772,7 @@ static int graph_batch(malcs_batch *b, const int64_t *shift, const int64_t *max_
                 if (runs[r].level < 0 || runs[r].level >= llcs) failed.store(1);
             }
             if (failed.load()) continue;
-            build_graph(B, store, m, n, sh, runs, runs.empty() ? 0 : llcs, G);
+            if (!G.dev_built) build_graph(B, store, m, n, sh, runs, runs.empty() ? 0 : llcs, G);
             if (trace) { ns_runs += (uint64_t)((tb - ta) * 1e6); ns_build += (uint64_t)((now_ms() - tb) * 1e6); }
         }
     };
@@ -798,10 +947,10 @@ int malcs_graphs_counts(const malcs_graphs *g, int64_t *counts)
 {
     if (!g || !counts) { malcs_set_error("NULL argument"); return MALCS_ERR_ARG; }
     for (size_t i = 0; i < g->g.size(); i++) {
-        counts[4 * i] = (int64_t)g->g[i].runs.size() / 4;
+        counts[4 * i] = (int64_t)g->g[i].n_runs();
         counts[4 * i + 1] = g->g[i].n_levels;
-        counts[4 * i + 2] = (int64_t)g->g[i].nodes.size() / 3;
-        counts[4 * i + 3] = (int64_t)g->g[i].edges.size() / 6;
+        counts[4 * i + 2] = (int64_t)g->g[i].n_nodes();
+        counts[4 * i + 3] = (int64_t)g->g[i].n_edges();
     }
     return MALCS_OK;
 }
@@ -828,15 +977,27 @@ int malcs_graphs_supremal(const malcs_graphs *g, int64_t *supremal4)
     if (!g->g[i].field.empty()) memcpy(dst, g->g[i].field.data(), g->g[i].field.size() * sizeof(int64_t)); \
     return MALCS_OK;
 
-int malcs_graphs_runs(const malcs_graphs *g, uint64_t i, int64_t *dst) { MALCS_COPY_OUT(runs) }
-int malcs_graphs_nodes(const malcs_graphs *g, uint64_t i, int64_t *dst) { MALCS_COPY_OUT(nodes) }
-int malcs_graphs_edges(const malcs_graphs *g, uint64_t i, int64_t *dst) { MALCS_COPY_OUT(edges) }
+int malcs_graphs_runs(const malcs_graphs *g, uint64_t i, int64_t *dst)
+{
+    if (g && i < g->g.size()) widen(const_cast<malcs_graphs *>(g), const_cast<malcs_graphs *>(g)->g[i]);
+    MALCS_COPY_OUT(runs)
+}
+int malcs_graphs_nodes(const malcs_graphs *g, uint64_t i, int64_t *dst)
+{
+    if (g && i < g->g.size()) widen(const_cast<malcs_graphs *>(g), const_cast<malcs_graphs *>(g)->g[i]);
+    MALCS_COPY_OUT(nodes)
+}
+int malcs_graphs_edges(const malcs_graphs *g, uint64_t i, int64_t *dst)
+{
+    if (g && i < g->g.size()) widen(const_cast<malcs_graphs *>(g), const_cast<malcs_graphs *>(g)->g[i]);
+    MALCS_COPY_OUT(edges)
+}
 
 int malcs_graphs_canonical_count(malcs_graphs *g, uint64_t i, int64_t *count)
 {
     if (!g || i >= g->g.size() || !count) { malcs_set_error("bad argument"); return MALCS_ERR_ARG; }
     if (g->g[i].status != MALCS_PAIR_OK) { malcs_set_error("pair %llu has no graph", (unsigned long long)i); return MALCS_ERR_ARG; }
-    if (!g->g[i].canon_done) canonical_of(g->g[i]);
+    if (!g->g[i].canon_done) { widen(g, g->g[i]); canonical_of(g->g[i]); }
     *count = (int64_t)g->g[i].canon.size() / 4;
     return MALCS_OK;
 }
@@ -851,10 +1012,18 @@ int malcs_graphs_canonical(malcs_graphs *g, uint64_t i, int64_t *dst)
     return MALCS_OK;
 }
 
+int malcs_graphs_device_built(const malcs_graphs *g, uint64_t *count, float *ms)
+{
+    if (!g) { malcs_set_error("NULL argument"); return MALCS_ERR_ARG; }
+    if (count) *count = g->n_dev_built;
+    if (ms) *ms = g->timing[3];
+    return MALCS_OK;
+}
+
 int malcs_graphs_timing(const malcs_graphs *g, float *out3)
 {
     if (!g || !out3) { malcs_set_error("NULL argument"); return MALCS_ERR_ARG; }
-    memcpy(out3, g->timing, sizeof(g->timing));
+    memcpy(out3, g->timing, 3 * sizeof(float));
     return MALCS_OK;
 }
 

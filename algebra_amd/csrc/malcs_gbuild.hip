@@ -1,0 +1,126 @@
+// malcs_gbuild.hip -- kernel family 2c: _build_graph on the device.
+//
+// Stands in for _build_graph(reference, observed, lcs_nodes, shift) (algebra/lcs/lcs_graph.py:351-453) for the pairs
+// whose optimal runs the sweep kernels (malcs_sweep.hip) have just left in device memory: the runs are ordered as the
+// reference's level lists (by level, sweep iteration, diagonal group, diagonal, row), the levels are
+// linked by strict dominance of the run ends (:398), nodes are split (:405-412) and re-inserted (:418-423), source and
+// sink are trimmed (:428-451), and the graph leaves in the numbering the C-ABI promises (BFS by identity from the
+// source, edges in Node.edges order).  What comes back to the host per pair is the finished node / edge arrays; the
+// host neither sorts nor links anything for these pairs.
+//
+// One wave per pair.
+//   * ordering: lane-parallel.  Every lane computes the sort keys of its runs and their ranks by counting the smaller
+//     keys (R^2 / 64 comparisons per lane against keys in LDS; R is a few dozen for a 1 kb window, at most 1 024 here);
+//   * construction: malcs_graph_core.hpp, the same source the host half compiles (so the two cannot drift apart), run
+//     by lane 0 on an arena in LDS (graphs of <= 64 runs; everything is a few dependent LDS accesses per step) or in a
+//     per-pair stretch of global scratch (up to 1 024 runs).  The construction is a chain of dependent list operations:
+//     its parallelism is across the pairs of a batch (thousands of waves in flight), not inside a pair;
+//   * output: lane 0 reserves the graph's words with one atomic add on a batch-wide cursor and writes nodes and edges
+//     there, so the host copies exactly what was produced.
+// A pair that does not fit (too many runs, arena overflow, output buffer full) is flagged and goes through the host
+// half (malcs_build.cpp), which gives the same result.
+#include "malcs_internal.hpp"
+#include "malcs_graph_core.hpp"
+
+namespace {
+
+constexpr int PAIR_OUT = 10;            // per slot: status, n_nodes, n_edges, supremal[4], out offset (lo, hi), n_runs
+
+// sort key of a run in the reference's emission order (malcs_build.cpp: order_runs)
+__device__ __forceinline__ void run_key(const int4 r, int32_t delta, uint64_t &k1, uint64_t &k2)
+{
+    const int32_t re = r.x + r.z, ce = r.y + r.z, diag = r.y - r.x;
+    const int32_t cost = re + ce - 2 * (r.w + 1);                        // forward edit cost of the corner after the run
+    const int32_t off = diag - delta, aoff = off < 0 ? -off : off, adelta = delta < 0 ? -delta : delta;
+    const int32_t it = (cost + aoff - adelta) / 2;                       // sweep iteration that first affords it
+    const uint32_t grp = diag < delta ? 0u : (diag > delta ? 1u : 2u);
+    const int32_t dk = grp == 0 ? diag : -diag;
+    k1 = ((uint64_t)(uint32_t)r.w << 32) | ((uint64_t)(uint32_t)it << 2) | grp;
+    k2 = ((uint64_t)(uint32_t)(dk + 0x40000000) << 32) | (uint32_t)r.x;
+}
+
+// RCAP: runs a pair may have; NC / EC / LC: capacities of the LDS arena (LDS_ARENA) -- otherwise the arena is the slot's
+// stretch of `scratch`, sized by the host from the slot's run count
+template <int RCAP, bool LDS_ARENA, int NC, int EC, int LC>
+__global__ void __launch_bounds__(64)
+k_graph_build(uint4 *__restrict__ runs, const uint64_t *__restrict__ run_off, const uint32_t *__restrict__ run_cnt,
+              const uint32_t *__restrict__ pids, const uint32_t *__restrict__ slots, uint32_t n_slots,
+              const uint32_t *__restrict__ a_len, const uint32_t *__restrict__ b_len, const int32_t *__restrict__ dist,
+              const int64_t *__restrict__ shift, int32_t *__restrict__ scratch, const uint64_t *__restrict__ scratch_off,
+              int32_t *__restrict__ out_words, unsigned long long out_cap, unsigned long long *__restrict__ out_cursor,
+              int32_t *__restrict__ pair_out)
+{
+    __shared__ uint64_t key1[RCAP], key2[RCAP];
+    __shared__ int32_t sorted[4 * RCAP];
+    __shared__ int32_t arena_mem[LDS_ARENA ? (9 * NC + 6 * EC + 2 * LC) : 1];
+    __shared__ int32_t bcast[4];
+    if (blockIdx.x >= n_slots) return;
+    const uint32_t slot = slots[blockIdx.x], lane = threadIdx.x;
+    const uint32_t R = run_cnt[slot], pid = pids[slot];
+    int32_t *po = pair_out + (size_t)slot * PAIR_OUT;
+    if (R == 0 || R > (uint32_t)RCAP) { if (lane == 0) { po[0] = 1; po[9] = (int32_t)R; } return; }
+    const int32_t m = (int32_t)a_len[pid], n = (int32_t)b_len[pid], delta = n - m;
+    uint4 *mine = runs + run_off[slot];
+    // keys of this lane's runs, then their ranks: the number of runs with a smaller key (keys are distinct)
+    for (uint32_t i = lane; i < R; i += 64) {
+        const uint4 u = mine[i];
+        run_key(make_int4((int)u.x, (int)u.y, (int)u.z, (int)u.w), delta, key1[i], key2[i]);
+    }
+    __syncthreads();
+    for (uint32_t i = lane; i < R; i += 64) {
+        const uint64_t a1 = key1[i], a2 = key2[i];
+        uint32_t rank = 0;
+        for (uint32_t j = 0; j < R; j++) rank += (key1[j] < a1 || (key1[j] == a1 && key2[j] < a2)) ? 1u : 0u;
+        const uint4 u = mine[i];
+        sorted[4 * rank] = (int32_t)u.x; sorted[4 * rank + 1] = (int32_t)u.y; sorted[4 * rank + 2] = (int32_t)u.z; sorted[4 * rank + 3] = (int32_t)u.w;
+    }
+    __syncthreads();
+    // the runs go back in order: they are the `runs` the handle exposes, and what the host half builds from if this
+    // kernel has to give the pair up
+    for (uint32_t i = lane; i < R; i += 64)
+        mine[i] = make_uint4((uint32_t)sorted[4 * i], (uint32_t)sorted[4 * i + 1], (uint32_t)sorted[4 * i + 2], (uint32_t)sorted[4 * i + 3]);
+    if (lane == 0) {
+        malcs_core::arena A;
+        if (LDS_ARENA) malcs_core::arena_bind(A, arena_mem, NC, EC, LC);
+        else malcs_core::arena_bind(A, scratch + scratch_off[slot], 2 * (int32_t)R + 16, 8 * (int32_t)R + 64, (int32_t)R + 8);
+        const int32_t n_levels = (m + n - dist[pid]) / 2;
+        int32_t source = 0, sink = 0, sup[4] = {0, 0, 0, 0};
+        malcs_core::build(A, m, n, shift ? shift[pid] : 0, sorted, (int32_t)R, n_levels, source, sink, sup);
+        int32_t status = A.overflow ? 1 : 0, count = 0, n_edges = 0;
+        unsigned long long at = 0;
+        if (!status) {
+            count = malcs_core::number_nodes(A, source, n_edges);
+            const unsigned long long words = 3ull * (unsigned)count + 6ull * (unsigned)n_edges;
+            at = atomicAdd(out_cursor, words);
+            if (at + words > out_cap) status = 1;                          // the output buffer is full: the host half takes the pair
+            else malcs_core::write_graph<int32_t>(A, count, out_words + at, out_words + at + 3ull * (unsigned)count, 0);
+        }
+        po[0] = status; po[1] = count; po[2] = n_edges; po[3] = sup[0]; po[4] = sup[1]; po[5] = sup[2]; po[6] = sup[3];
+        po[7] = (int32_t)(uint32_t)at; po[8] = (int32_t)(uint32_t)(at >> 32); po[9] = (int32_t)R;
+    }
+    (void)bcast;
+}
+
+}  // namespace
+
+int malcs_gbuild_pair_out_words() { return PAIR_OUT; }
+
+// small: graphs of at most 64 runs on an arena in LDS; otherwise at most 1 024 runs on an arena in `scratch`
+int malcs_gbuild_launch(malcs_ctx *ctx, bool small, uint4 *d_runs, const uint64_t *d_run_off, const uint32_t *d_run_cnt,
+                        const uint32_t *d_pids, const uint32_t *d_slots, uint32_t n_slots, const uint32_t *d_a_len,
+                        const uint32_t *d_b_len, const int32_t *d_dist, const int64_t *d_shift, int32_t *d_scratch,
+                        const uint64_t *d_scratch_off, int32_t *d_out_words, uint64_t out_cap, unsigned long long *d_out_cursor,
+                        int32_t *d_pair_out)
+{
+    if (!n_slots) return MALCS_OK;
+    if (small)
+        hipLaunchKernelGGL((k_graph_build<64, true, 112, 288, 72>), dim3(n_slots), dim3(64), 0, ctx->stream, d_runs, d_run_off, d_run_cnt,
+                           d_pids, d_slots, n_slots, d_a_len, d_b_len, d_dist, d_shift, d_scratch, d_scratch_off, d_out_words,
+                           (unsigned long long)out_cap, d_out_cursor, d_pair_out);
+    else
+        hipLaunchKernelGGL((k_graph_build<1024, false, 1, 1, 1>), dim3(n_slots), dim3(64), 0, ctx->stream, d_runs, d_run_off, d_run_cnt,
+                           d_pids, d_slots, n_slots, d_a_len, d_b_len, d_dist, d_shift, d_scratch, d_scratch_off, d_out_words,
+                           (unsigned long long)out_cap, d_out_cursor, d_pair_out);
+    MALCS_HIP(hipGetLastError());
+    return MALCS_OK;
+}

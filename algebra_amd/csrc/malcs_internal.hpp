@@ -8,6 +8,9 @@
 #include <cstdio>
 #include <cstdlib>
 #include <vector>
+#include <algorithm>
+#include <cstring>
+#include <new>
 #include "../../include/malcs.h"
 
 void malcs_set_error(const char *fmt, ...);
@@ -73,6 +76,41 @@ struct malcs_ctx {
     std::vector<uint64_t> seq_byte_off;
     std::vector<uint32_t> seq_len, seq_blk_off;
     std::vector<struct malcs_batch *> spare_batches;
+};
+
+// Pinned host memory from a process-wide pool (blocks are kept when they are released: pinning a hundred megabytes
+// costs tens of milliseconds, and results that come home into pageable memory pay for every fresh page).
+void *malcs_pinned_alloc(size_t bytes);        // nullptr when the runtime has none to give
+void malcs_pinned_free(void *p);
+
+// a growable array in pinned memory (what device results are copied into and then read from in place)
+template <typename T> struct pinned_vec {
+    T *p = nullptr;
+    size_t n = 0, cap = 0;
+    pinned_vec() = default;
+    pinned_vec(const pinned_vec &) = delete;
+    pinned_vec &operator=(const pinned_vec &) = delete;
+    pinned_vec(pinned_vec &&o) noexcept : p(o.p), n(o.n), cap(o.cap) { o.p = nullptr; o.n = o.cap = 0; }
+    ~pinned_vec() { if (p) malcs_pinned_free(p); }
+    size_t size() const { return n; }
+    bool empty() const { return n == 0; }
+    T *data() { return p; }
+    const T *data() const { return p; }
+    T &operator[](size_t i) { return p[i]; }
+    const T &operator[](size_t i) const { return p[i]; }
+    void clear() { n = 0; }
+    void resize(size_t m)                          // new elements are NOT initialised
+    {
+        if (m > cap) {
+            const size_t want = std::max(m, cap + cap / 2);
+            T *q = static_cast<T *>(malcs_pinned_alloc(std::max<size_t>(want, 1) * sizeof(T)));
+            if (!q) throw std::bad_alloc();
+            if (n) memcpy(q, p, n * sizeof(T));
+            if (p) malcs_pinned_free(p);
+            p = q; cap = want;
+        }
+        n = m;
+    }
 };
 
 // Pooled device memory of a context (the context's device must be current).  malcs_pool_free never synchronises: the
@@ -177,4 +215,13 @@ int malcs_dist_launch_list(hipStream_t st, int n_planes, int W, int L, const uin
                            int32_t *d_dist);
 
 // malcs_sweep.hip
+// A chunk of pairs whose optimal runs have just been compacted in device memory (before they are copied to the host):
+// slot f has runs d_runs[run_off[f] .. + cnt[f]) = {row, col, length, level}, belongs to pair pids[f] and to entry
+// work_index[f] of the caller's work list.
+struct malcs_sweep_chunk {
+    uint4 *d_runs; const uint64_t *d_run_off; const uint32_t *d_run_cnt; const uint32_t *d_pids;
+    uint32_t count;
+    const uint32_t *pids, *cnt; const uint64_t *run_off, *work_index;      // host copies
+};
+typedef int (*malcs_sweep_hook)(void *user, const malcs_sweep_chunk &chunk);
 int malcs_sweep_distances(malcs_batch *b, const std::vector<uint32_t> &pairs, int32_t cap, std::vector<int32_t> &out);

@@ -641,7 +641,8 @@ int malcs_sweep_distances(malcs_batch *b, const std::vector<uint32_t> &pairs, in
 // With unknown_cap > 0 the distances are not known yet: the backward sweep runs up to that many edits, writes what
 // it finds to dist[pid] (-1: more than unknown_cap, no runs for that pair) and sizes its table for the cap.
 int malcs_sweep_optimal_runs(malcs_batch *b, bool small, const std::vector<uint32_t> &work, int32_t *dist, int32_t unknown_cap,
-                             std::vector<uint32_t> &out_runs, std::vector<uint64_t> &out_first, float *ms)
+                             pinned_vec<uint32_t> &out_runs, std::vector<uint64_t> &out_first, float *ms,
+                             malcs_sweep_hook hook, void *hook_user)
 {
     const int lds_diags = small ? SMALL_DIAGS : BIG_DIAGS;
     hipStream_t st = b->ctx->stream;
@@ -780,7 +781,16 @@ int malcs_sweep_optimal_runs(malcs_batch *b, bool small, const std::vector<uint3
             MALCS_HIP(malcs_h2d(st, d_packed_off.p, packed_off.data(), cntf * 8ull));
             rc = malcs_graph_launch_compact(ctx, d_out.p, d_out_off.p, d_cnt.p, d_packed_off.p, cntf, d_packed.p);
             if (rc) return rc;
-            MALCS_HIP(malcs_d2h(st, out_runs.data() + base, d_packed.p, kept * 16ull));
+            if (hook) {
+                // the runs of this chunk sit compacted in device memory: whoever wants to go on with them there (the graph
+                // kernels of malcs_gbuild.hip, which also leave them sorted) does so before they come home
+                std::vector<uint64_t> index(cntf);
+                for (uint32_t f = 0; f < cntf; f++) index[f] = pos + keep[f];
+                malcs_sweep_chunk chunk{d_packed.p, d_packed_off.p, d_cnt.p, d_work.p, cntf, fwd_work.data(), got.data(), packed_off.data(), index.data()};
+                rc = hook(hook_user, chunk);
+                if (rc) return rc;
+            }
+            MALCS_HIP(hipMemcpyAsync(out_runs.data() + base, d_packed.p, kept * 16ull, hipMemcpyDeviceToHost, st));   // pinned destination
             MALCS_HIP(malcs_sync(st));
             stages.lap("compaction, runs to the host");
         }

@@ -191,6 +191,10 @@ int malcs_graphs_canonical(malcs_graphs *graphs, uint64_t i, int64_t *variants4)
 /* timing split of the last malcs_lcs_graph_batch on this handle, milliseconds:
  * out[0] forward DP kernel, out[1] reach/extract kernel (HIP events), out[2] D2H + host graph build */
 int malcs_graphs_timing(const malcs_graphs *graphs, float *out3);
+/* how many of the handle's graphs were constructed on the device (kernel family 2c, malcs_gbuild.hip: ordering of
+ * the runs, dominance edges, splits, numbering -- the host only copies the arrays home), and the kernels'
+ * milliseconds (HIP events); the others went through the host half.  Either pointer may be NULL. */
+int malcs_graphs_device_built(const malcs_graphs *graphs, uint64_t *count, float *ms);
 
 /* ---- kernel family 3: tiles of the all-vs-all relation matrix -----------------------------------
  * Stands in for graph_based.compare (algebra/relations/graph_based.py:33-79) over all pairs of a list of n LCS graphs

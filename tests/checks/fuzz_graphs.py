@@ -30,7 +30,7 @@ for label, env in (("default", {}), ("sweep-all", {"MALCS_SWEEP_MIN_ROWS": "1", 
     os.environ.update(env)
     bt = N.Batch(ctx, *data)
     t0 = time.time(); res = bt.graphs(np.array(shifts, np.int64)); dt = time.time() - t0
-    print(f"{label}: {n_pairs} pairs in {dt:.2f}s, {int(res.counts[:, 3].sum())} edges", flush=True)
+    print(f"{label}: {n_pairs} pairs in {dt:.2f}s, {int(res.counts[:, 3].sum())} edges, {res.device_built} graphs built on the device", flush=True)
     results.append((label, res)); bt.close()
 bad = 0
 t0 = time.time()

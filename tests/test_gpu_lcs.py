@@ -568,3 +568,33 @@ def test_graph_long_windows_any_alphabet(native, alphabet, path, monkeypatch):
         assert res.distance[i] == ref.distance and tuple(res.supremal[i]) == ref.supremal, i
         assert np.array_equal(res.nodes(i), ref.nodes) and np.array_equal(res.edges(i), ref.edges), i
     res.close()
+
+
+def test_graphs_built_on_the_device_match_the_host_half(native, monkeypatch):
+    """Kernel family 2c (malcs_gbuild.hip): ordering of the runs, dominance edges, splits, trimming and numbering on
+    the device against the host half of the library (same pairs, MALCS_GBUILD=0) and against the oracle."""
+    from oracle import oracle as O
+    data = gen.c2_batch(3000, seed=31)
+    shifts = np.arange(3000, dtype=np.int64) % 7
+    ctx = native.default_context()
+    batch = native.Batch(ctx, *data, 4)
+    dev = batch.graphs(shifts)
+    monkeypatch.setenv("MALCS_GBUILD", "0")
+    host = batch.graphs(shifts)
+    monkeypatch.delenv("MALCS_GBUILD")
+    batch.close()
+    try:
+        assert dev.device_built == 3000 and host.device_built == 0
+        assert np.array_equal(dev.counts, host.counts) and np.array_equal(dev.supremal, host.supremal)
+        assert np.array_equal(dev.distance, host.distance)
+        syms, a_off, a_len, b_off, b_len = data
+        for i in range(3000):
+            assert np.array_equal(dev.nodes(i), host.nodes(i)) and np.array_equal(dev.edges(i), host.edges(i)), i
+            assert np.array_equal(dev.runs(i), host.runs(i)), i
+            if i % 50 == 0:
+                ref = O.lcs_graph(syms[int(a_off[i]):int(a_off[i]) + int(a_len[i])], syms[int(b_off[i]):int(b_off[i]) + int(b_len[i])], int(shifts[i]))
+                assert tuple(dev.supremal[i]) == ref.supremal and np.array_equal(dev.nodes(i), ref.nodes) and np.array_equal(dev.edges(i), ref.edges)
+                assert np.array_equal(dev.canonical(i), host.canonical(i))
+    finally:
+        dev.close()
+        host.close()
