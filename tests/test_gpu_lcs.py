@@ -598,3 +598,51 @@ def test_graphs_built_on_the_device_match_the_host_half(native, monkeypatch):
     finally:
         dev.close()
         host.close()
+
+
+@pytest.mark.parametrize("path", ["sweep", "band"])
+def test_c5_ii_one_megabase_two_percent(native, path, monkeypatch):
+    """BASELINE config 5 (ii): one 1 Mb pair at 2 % indels (D about 20 000) on both device paths.
+    PARITY UNPINNED AGAINST THE REFERENCE: it cannot run this size (about 1e10 interpreted cell steps), and neither
+    can the oracle's `_lcs_nodes` restatement, which keeps every run the sweep passes (killed at 64 GB here).
+    What is checked instead: the distance against the oracle's O(NP) `edit_distance`; the graph against the
+    oracle's independent `_build_graph` fed with the runs the device found; that those runs are matches, lie on
+    consecutive levels and number LLCS levels; and the round trip -- the canonical allele patched into the reference
+    spells the observed sequence, at a cost equal to the distance."""
+    from oracle import oracle as O
+    from algebra_amd.lcs.encoding import encode_pairs
+    use_path(monkeypatch, path)
+    rs = np.random.RandomState(55)
+    a = gen.random_seq(rs, 1000000)
+    b = gen.mutate(rs, a, 0.01, 0.01)
+    ctx = native.default_context()
+    batch = native.Batch(ctx, *encode_pairs([(a, b)]))
+    res = batch.graphs()
+    batch.close()
+    try:
+        want = O.edit_distance(a, b)
+        assert int(res.distance[0]) == want and 15000 < want < 25000
+        runs, nodes, edges = res.runs(0), res.nodes(0), res.edges(0)
+        llcs = (len(a) + len(b) - want) // 2
+        assert int(res.counts[0, 1]) == llcs
+        # every run is a diagonal stretch of equal symbols ending on its level; together they cover all levels
+        an, bn = np.frombuffer(a.encode(), np.uint8), np.frombuffer(b.encode(), np.uint8)
+        covered = np.zeros(llcs + 1, np.int64)
+        for row, col, length, level in runs[:: max(1, len(runs) // 4000)].tolist():
+            assert np.array_equal(an[row:row + length], bn[col:col + length])
+        np.add.at(covered, runs[:, 3] - runs[:, 2] + 1, 1)
+        np.add.at(covered, runs[:, 3] + 1, -1)
+        assert (np.cumsum(covered)[:llcs] > 0).all()
+        ref = O.graph_from_runs(len(a), len(b), 0, runs, llcs, want)
+        assert ref.supremal == tuple(res.supremal[0])
+        assert np.array_equal(ref.nodes, nodes) and np.array_equal(ref.edges, edges)
+        canon = res.canonical(0)
+        pieces, pos, cost = [], 0, 0
+        for start, end, lo, hi in canon.tolist():
+            assert start >= pos
+            pieces += [a[pos:start], b[lo:hi]]
+            pos = end
+            cost += (end - start) + (hi - lo)
+        assert "".join(pieces + [a[pos:]]) == b and cost >= want
+    finally:
+        res.close()

@@ -347,3 +347,31 @@ def test_compare_matrix_all_gather_on_device_memory():
     proc.join(timeout=60)
     assert proc.exitcode == 0
     assert ok and all(ok)
+
+
+def test_compare_matrix_c4_full_size():
+    """BASELINE config 4 at the size bench.py times: 5 000 clustered variants in a 100 kb locus, all 12 497 500 pairs
+    against what the reference returned for them (tests/golden/c4_matrix.json, made by make_golden_c4.py): supremals and
+    distances of the 5 000 graphs, SHA-256 and histogram of the upper triangle, 3 000 explicit labels below the
+    diagonal, the diagonal."""
+    import hashlib
+    from conftest import load_golden
+    from util import digest
+    from algebra_amd.lcs import LCSgraph
+    from algebra_amd.relations import compare_matrix
+    from algebra_amd.variants import Variant
+    gold = load_golden("c4_matrix.json")
+    case = gen.matrix_case(**gold["params"])
+    assert digest([case["reference"], [list(v) for v in case["variants"]]]) == gold["input_sha256"]
+    graphs = LCSgraph.from_variant_batch(case["reference"], [[Variant(*v)] for v in case["variants"]])
+    assert digest([[g.supremal.start, g.supremal.end, g.supremal.sequence] for g in graphs]) == gold["supremals_sha256"]
+    assert digest([g.distance for g in graphs]) == gold["distances_sha256"]
+    labels = compare_matrix(case["reference"], graphs)
+    n = gold["n"]
+    assert labels.shape == (n, n)
+    upper = labels[np.triu_indices(n, 1)]                              # row-major, i < j
+    assert np.bincount(upper, minlength=5).tolist() == gold["upper_histogram"]
+    assert hashlib.sha256(np.ascontiguousarray(upper, dtype=np.uint8).tobytes()).hexdigest() == gold["upper_sha256"]
+    assert (np.diagonal(labels) == 0).all()                            # a graph is equivalent to itself
+    for j, i, code in gold["below_diagonal_sample"]:
+        assert labels[j, i] == code, (j, i)
