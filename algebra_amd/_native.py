@@ -75,6 +75,12 @@ def _load():
         "malcs_relmatrix_assemble": (c.c_int, [vp, vp, vp]),
         "malcs_relmatrix_tiles_device": (c.c_int, [vp, P(vp), P(u64)]),
         "malcs_relmatrix_assemble_device": (c.c_int, [vp, vp, vp]),
+        "malcs_relmatrix_assemble_comm": (c.c_int, [vp, vp, vp]),
+        "malcs_comm_unique_id": (c.c_int, [vp]),
+        "malcs_comm_create": (c.c_int, [vp, vp, c.c_int, c.c_int, P(vp)]),
+        "malcs_comm_destroy": (c.c_int, [vp]),
+        "malcs_comm_info": (c.c_int, [vp, P(c.c_int), P(c.c_int)]),
+        "malcs_comm_all_gather": (c.c_int, [vp, vp, vp, u64]),
     }
     for name, (res, args) in sig.items():
         fn = getattr(lib, name)          # AttributeError here = header and library disagree
@@ -88,12 +94,13 @@ lib, EXPORTS = _load()
 
 # Handles still open at interpreter exit are released here, in dependency order, while the HIP
 # runtime is still alive (its own teardown runs after Python's).
-_live = {"graphs": weakref.WeakSet(), "relmatrix": weakref.WeakSet(), "batch": weakref.WeakSet(), "ctx": weakref.WeakSet()}
+_live = {"graphs": weakref.WeakSet(), "relmatrix": weakref.WeakSet(), "batch": weakref.WeakSet(), "comm": weakref.WeakSet(),
+         "ctx": weakref.WeakSet()}
 
 
 @atexit.register
 def _close_all():
-    for kind in ("graphs", "relmatrix", "batch", "ctx"):
+    for kind in ("graphs", "relmatrix", "batch", "comm", "ctx"):
         for obj in list(_live[kind]):
             try:
                 obj.close()
@@ -305,6 +312,37 @@ def graphs_from_runs(m, n, shift, n_levels, runs4, run_first):
     return Graphs(handle, len(m))
 
 
+def comm_unique_id():
+    """The 128 bytes rank 0 hands to the other ranks of a job (ncclGetUniqueId)."""
+    buf = ctypes.create_string_buffer(128)
+    check(lib.malcs_comm_unique_id(buf))
+    return buf.raw
+
+
+class Comm:
+    """This rank's end of the job's RCCL communicator (malcs_comm): one per process, on its context."""
+
+    def __init__(self, ctx, unique_id, rank, world):
+        if len(unique_id) != 128:
+            raise ValueError("the communicator id has 128 bytes")
+        self.ctx, self.rank, self.world = ctx, int(rank), int(world)
+        self.handle = ctypes.c_void_p()
+        check(lib.malcs_comm_create(ctx.handle, ctypes.c_char_p(unique_id), self.rank, self.world, ctypes.byref(self.handle)))
+        _live["comm"].add(self)
+
+    def close(self):
+        if self.handle:
+            if self.ctx.handle:
+                lib.malcs_comm_destroy(self.handle)
+            self.handle = ctypes.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
 class RelationMatrix:
     """This rank's tiles of the all-vs-all relation matrix on the device (malcs_relmatrix)."""
 
@@ -355,6 +393,12 @@ class RelationMatrix:
             raise ValueError("gathered label block has the wrong size")
         full = np.zeros((self.n, self.n), dtype=np.uint8)
         check(lib.malcs_relmatrix_assemble_device(self.handle, ctypes.c_void_p(address), ptr(full)))
+        return full
+
+    def assemble_comm(self, comm):
+        """All-gather of every rank's label block over RCCL (the library's own collective) + assembly."""
+        full = np.zeros((self.n, self.n), dtype=np.uint8)
+        check(lib.malcs_relmatrix_assemble_comm(self.handle, comm.handle, ptr(full)))
         return full
 
     def assemble(self, gathered=None):

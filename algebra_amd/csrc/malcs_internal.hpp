@@ -225,3 +225,9 @@ struct malcs_sweep_chunk {
 };
 typedef int (*malcs_sweep_hook)(void *user, const malcs_sweep_chunk &chunk);
 int malcs_sweep_distances(malcs_batch *b, const std::vector<uint32_t> &pairs, int32_t cap, std::vector<int32_t> &out);
+
+// malcs_comm.cpp
+int malcs_comm_all_gather_async(malcs_comm *c, const void *d_send, void *d_recv, uint64_t bytes);
+int malcs_comm_world(const malcs_comm *c);
+int malcs_comm_rank(const malcs_comm *c);
+malcs_ctx *malcs_comm_ctx(const malcs_comm *c);

@@ -268,6 +268,26 @@ int malcs_relmatrix_assemble(malcs_relmatrix *h, const uint8_t *gathered, uint8_
     return relmatrix_assemble(h, d_gathered.p, full);
 }
 
+int malcs_relmatrix_assemble_comm(malcs_relmatrix *h, malcs_comm *comm, uint8_t *full)
+{
+    if (!h || !comm || (h->n && !full)) { malcs_set_error("NULL argument"); return MALCS_ERR_ARG; }
+    if (malcs_comm_ctx(comm) != h->ctx || (uint32_t)malcs_comm_world(comm) != h->world || (uint32_t)malcs_comm_rank(comm) != h->rank) {
+        malcs_set_error("the communicator (rank %d of %d) does not match the tiles (rank %u of %u) or their context",
+                        malcs_comm_rank(comm), malcs_comm_world(comm), h->rank, h->world);
+        return MALCS_ERR_ARG;
+    }
+    if (!h->n) return MALCS_OK;
+    MALCS_HIP(hipSetDevice(h->ctx->device));
+    // stream order does the rest: resolve() scattered the verdicts on this stream, the collective reads this rank's
+    // block where they were written and writes everybody's where the assembly kernel reads them
+    const size_t block = (size_t)h->per_rank * h->tile * h->tile;
+    dev<uint8_t> d_gathered;
+    if (d_gathered.alloc(block * h->world)) { malcs_set_error("device allocation failed (%llu gathered label bytes)", (unsigned long long)(block * h->world)); return MALCS_ERR_NOMEM; }
+    const int rc = malcs_comm_all_gather_async(comm, h->labels.p, d_gathered.p, block);
+    if (rc) return rc;
+    return relmatrix_assemble(h, d_gathered.p, full);
+}
+
 int malcs_relmatrix_assemble_device(malcs_relmatrix *h, const void *d_gathered, uint8_t *full)
 {
     if (!h || (h->n && !full) || !d_gathered) { malcs_set_error("NULL argument"); return MALCS_ERR_ARG; }

@@ -8,9 +8,10 @@ edit distances (:65, kernel family 1); the few that the distance arithmetic (:67
 look at atom masks (:76-79); the device scatters the verdicts into the label tiles and assembles
 the full matrix.
 
-Multi-GPU: upper-triangular tiles are dealt round-robin to the ranks of a torch.distributed
-group (one process per GPU).  The only collective is one all-gather of the uint8 label tiles
-(RCCL over xGMI with the "nccl" backend; "gloo" in the CPU tests).
+Multi-GPU: upper-triangular tiles are dealt round-robin to the ranks of a job (one process per GPU).  The only
+collective is one all-gather of the uint8 label tiles: RCCL over xGMI, called by the library itself on its own
+buffers (`comm` = `algebra_amd.comm.init()`, malcs_relmatrix_assemble_comm).  Nothing here imports torch; a caller
+with another transport passes `rank`, `world` and a `gather` function (the CPU tests do, with gloo).
 """
 
 import numpy as np
@@ -34,13 +35,6 @@ def upper_tiles(n, tile):
 def shard(items, rank, world):
     """Round-robin deal of work items to ranks."""
     return items[rank::world]
-
-
-class _DeviceBytes:
-    """A span of device memory owned by the library, as the CUDA array interface torch reads."""
-
-    def __init__(self, address, nbytes):
-        self.__cuda_array_interface__ = {"shape": (nbytes,), "typestr": "|u1", "data": (address, False), "version": 2}
 
 
 class Prepared:
@@ -69,29 +63,28 @@ class Prepared:
         self.symmask = np.array(masks, dtype=np.uint64)
 
 
-def compare_matrix(reference, graphs, tile=256, group=None, distance_fn=None, stats=None, tiles_cls=None, gather_always=False):
+def compare_matrix(reference, graphs, tile=256, comm=None, rank=0, world=1, gather=None, distance_fn=None, stats=None,
+                   tiles_cls=None):
     """uint8 matrix L with L[i, j] = code of compare(reference, graphs[i], graphs[j]).
 
     Codes follow the order of `Relation` (0 equivalent, 1 contains, 2 is_contained, 3 overlap,
-    4 disjoint).  With an initialised torch.distributed process group (or `group`), the tiles are
-    sharded over its ranks and all-gathered; every rank returns the full matrix.
+    4 disjoint).  In a job of several ranks the tiles are sharded over them and all-gathered; every rank
+    returns the full matrix.  `comm` is this rank's `_native.Comm` (`algebra_amd.comm.init()`): the library runs the
+    all-gather over RCCL on its own device buffers (also in a job of one rank, where it is a copy).  Without a
+    communicator, `rank` / `world` say whose tiles to compute and `gather(block)` exchanges them: it takes this
+    rank's (tiles_per_rank, tile, tile) uint8 block and returns every rank's, stacked in rank order.
 
-    `distance_fn` and `tiles_cls` exist for the host-logic tests (CPU, gloo): they inject
+    `distance_fn` and `tiles_cls` exist for the host-logic tests (CPU): they inject
     distances computed elsewhere and a numpy restatement of the tile kernels.  The product path
-    leaves both unset and runs on the device.  `gather_always` runs the collective in a group of one rank as well
-    (tests of the RCCL path on a single GPU).
+    leaves both unset and runs on the device.
     """
     if distance_fn is None:
         from ..lcs import edit_distance_batch as distance_fn
     n = len(graphs)
-    rank, world, dist = 0, 1, None
-    try:
-        import torch.distributed as dist_mod
-        if dist_mod.is_available() and dist_mod.is_initialized():
-            dist = dist_mod
-            rank, world = dist.get_rank(group), dist.get_world_size(group)
-    except ImportError:
-        pass
+    if comm is not None:
+        rank, world = comm.rank, comm.world
+    elif world > 1 and gather is None:
+        raise ValueError("a job of several ranks needs a communicator or a gather function")
 
     import time
     clock = [time.perf_counter()]
@@ -142,36 +135,13 @@ def compare_matrix(reference, graphs, tile=256, group=None, distance_fn=None, st
             stats["tiles"] = len(shard(upper_tiles(n, tile), rank, world))
 
         # all-gather of the label tiles
+        if comm is not None:
+            full = tiles.assemble_comm(comm)
+            lap("all_gather_assemble")
+            return full
         gathered = None
-        if world > 1 or gather_always:
-            import torch
-            backend = dist.get_backend(group)
-            send = None
-            if backend == "nccl" and hasattr(tiles, "tiles_device"):
-                # RCCL reads this rank's block where the kernels wrote it and writes the gathered blocks where
-                # the assembly kernel reads them: no host staging.  (Every rank takes the same branch: wrapping the
-                # library's memory either works in this build of torch or it does not.)
-                address, nbytes = tiles.tiles_device()
-                device = torch.device("cuda", torch.cuda.current_device())
-                try:
-                    send = torch.as_tensor(_DeviceBytes(address, nbytes), device=device)
-                except (TypeError, RuntimeError, ValueError):
-                    send = None
-            if send is not None:
-                recv = torch.empty(world * nbytes, dtype=torch.uint8, device=device)
-                dist.all_gather_into_tensor(recv, send, group=group)
-                torch.cuda.current_stream(device).synchronize()
-                lap("all_gather")
-                full = tiles.assemble_device(recv.data_ptr(), recv.numel())
-                lap("assemble")
-                return full
-            mine = tiles.tiles()
-            send = torch.from_numpy(mine)
-            recv = torch.empty((world * mine.shape[0], tile, tile), dtype=torch.uint8)
-            if backend == "nccl":
-                send, recv = send.cuda(), recv.cuda()
-            dist.all_gather_into_tensor(recv, send, group=group)
-            gathered = recv.cpu().numpy()
+        if world > 1:
+            gathered = np.ascontiguousarray(gather(tiles.tiles()), dtype=np.uint8)
             lap("all_gather")
         full = tiles.assemble(gathered)
         lap("assemble")

@@ -141,10 +141,11 @@ def extra_configs(ctx, _native, gen):
     return out
 
 
-def relation_matrix(ctx, gen, world, fence, all_max):
+def relation_matrix(ctx, gen, rank, world, comm, gather, fence, all_max):
     """BASELINE config 4, the other half of the metric: the 5 000 x 5 000 `graph_based.compare` matrix over clustered
     variants in a 100 kb locus.  Upper-triangular 256 x 256 tiles are dealt round-robin to the ranks; the one
-    collective is the all-gather of the uint8 label tiles (RCCL); every rank ends with the full matrix.  Strong
+    collective is the all-gather of the uint8 label tiles (ncclAllGather, called by the library on its own buffers:
+    `comm`; the gloo rehearsal on one card passes `gather` instead); every rank ends with the full matrix.  Strong
     scaling of a 12 ms job: the per-rank share shrinks, preparation / all-gather / assembly do not."""
     from algebra_amd.lcs import LCSgraph
     from algebra_amd.relations import compare_matrix
@@ -153,7 +154,8 @@ def relation_matrix(ctx, gen, world, fence, all_max):
     t0 = time.perf_counter()
     graphs = LCSgraph.from_variant_batch(case["reference"], [[Variant(*v)] for v in case["variants"]], ctx=ctx)
     t_graphs = time.perf_counter() - t0
-    compare_matrix(case["reference"], graphs)                  # warm-up (code objects, atom masks of the graphs, communicator)
+    how = {"comm": comm, "rank": rank, "world": world, "gather": gather}
+    compare_matrix(case["reference"], graphs, **how)           # warm-up (code objects, atom masks of the graphs, communicator)
     import gc
     reps, stats = 5, {}
     gc.collect()
@@ -161,7 +163,7 @@ def relation_matrix(ctx, gen, world, fence, all_max):
     fence()
     t1 = time.perf_counter()
     for _ in range(reps):
-        labels = compare_matrix(case["reference"], graphs, stats=stats)
+        labels = compare_matrix(case["reference"], graphs, stats=stats, **how)
     seconds = all_max(time.perf_counter() - t1) / reps
     gc.enable()
     fence()
@@ -321,7 +323,21 @@ def main():
     assert np.array_equal(d_once, d)
 
     # the relation matrix is a job of all ranks (sharded tiles + all-gather): every rank takes part
-    matrix = None if args.no_extra else relation_matrix(ctx, gen, world, fence, all_max)
+    matrix = None
+    if not args.no_extra:
+        comm = gather = None
+        if world > 1 and args.backend == "nccl":
+            from algebra_amd import comm as job
+            comm = job.init(ctx, rank=rank, world=world)      # the library's own RCCL communicator (no torch in that path)
+        elif world > 1:
+            def gather(block):                                 # rehearsal on one card: gloo carries the label blocks
+                send = torch.from_numpy(np.ascontiguousarray(block))
+                recv = torch.empty((world * block.shape[0],) + tuple(block.shape[1:]), dtype=torch.uint8)
+                dist.all_gather_into_tensor(recv, send)
+                return recv.numpy()
+        matrix = relation_matrix(ctx, gen, rank, world, comm, gather, fence, all_max)
+        if comm is not None:
+            comm.close()
 
     if rank == 0:
         # HBM bytes per launch of that kernel: NOT measured in this run (counters need rocprofv3 passes of their own);

@@ -230,6 +230,24 @@ int malcs_relmatrix_assemble(malcs_relmatrix *m, const uint8_t *gathered, uint8_
 int malcs_relmatrix_tiles_device(const malcs_relmatrix *m, const void **d_labels, uint64_t *bytes);
 int malcs_relmatrix_assemble_device(malcs_relmatrix *m, const void *d_gathered, uint8_t *full);
 
+/* ---- the one collective: all-gather of the label tiles over RCCL ---------------------------------------
+ * NO COUNTERPART IN THE REFERENCE (it is single-threaded, single-process).  One process per GPU; the ranks of a job
+ * meet through a 128-byte id: rank 0 calls malcs_comm_unique_id and carries the bytes to the others (any channel:
+ * algebra_amd/comm.py uses a TCP socket at MASTER_ADDR), then every rank calls malcs_comm_create on its own context.
+ * librccl.so is loaded when the first of these is called (MALCS_RCCL_LIB overrides the name); the collective runs
+ * on the context's stream on the library's own buffers.
+ *   all_gather       `bytes` bytes at device address d_send of every rank -> world * bytes at d_recv (rank-major);
+ *                    returns when it is complete
+ *   malcs_relmatrix_assemble_comm   tiles (above) -> ncclAllGather of every rank's label block -> assemble: every
+ *                    rank ends with the full n x n matrix in `full`; nothing is staged through the host. */
+typedef struct malcs_comm malcs_comm;
+int malcs_comm_unique_id(void *id128);
+int malcs_comm_create(malcs_ctx *ctx, const void *id128, int rank, int world, malcs_comm **comm);
+int malcs_comm_destroy(malcs_comm *comm);
+int malcs_comm_info(const malcs_comm *comm, int *rank, int *world);
+int malcs_comm_all_gather(malcs_comm *comm, const void *d_send, void *d_recv, uint64_t bytes);
+int malcs_relmatrix_assemble_comm(malcs_relmatrix *m, malcs_comm *comm, uint8_t *full);
+
 #ifdef __cplusplus
 }
 #endif

@@ -286,7 +286,8 @@ def _matrix_rank(rank, world, port, out):
         case = SEQS["matrices"][0]
         graphs = LCSgraph.from_variant_batch(case["reference"], [[Variant(*v)] for v in case["variants"]])
         stats = {}
-        labels = compare_matrix(case["reference"], graphs, tile=8, stats=stats)
+        from util import gloo_gather
+        labels = compare_matrix(case["reference"], graphs, tile=8, rank=rank, world=world, gather=gloo_gather(dist), stats=stats)
         out.put((rank, labels.tolist() == case["labels"], stats["tiles"], stats["dp_pairs"]))
     finally:
         dist.destroy_process_group()
@@ -312,41 +313,39 @@ def test_compare_matrix_two_ranks_on_the_device():
 
 def _matrix_rccl_rank(port, out):
     import os
-    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), MALCS_DEVICE="0")
-    import torch
-    import torch.distributed as dist
-    torch.cuda.set_device(0)
-    dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", 0))
-    try:
-        from algebra_amd.lcs import LCSgraph
-        from algebra_amd.relations import compare_matrix
-        from algebra_amd.variants import Variant
-        ok = []
-        for case in SEQS["matrices"]:
-            graphs = LCSgraph.from_variant_batch(case["reference"], [[Variant(*v)] for v in case["variants"]])
-            for tile in (8, 256):
-                stats = {}
-                labels = compare_matrix(case["reference"], graphs, tile=tile, stats=stats, gather_always=True)
-                ok.append(labels.tolist() == case["labels"] and "seconds_all_gather" in stats)
-        out.put(ok)
-    finally:
-        dist.destroy_process_group()
+    import sys
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), MALCS_DEVICE="0", RANK="0", WORLD_SIZE="1")
+    from algebra_amd import comm as job
+    from algebra_amd.lcs import LCSgraph
+    from algebra_amd.relations import compare_matrix
+    from algebra_amd.variants import Variant
+    comm = job.init()
+    ok = []
+    for case in SEQS["matrices"]:
+        graphs = LCSgraph.from_variant_batch(case["reference"], [[Variant(*v)] for v in case["variants"]])
+        for tile in (8, 256):
+            stats = {}
+            labels = compare_matrix(case["reference"], graphs, tile=tile, comm=comm, stats=stats)
+            ok.append(labels.tolist() == case["labels"] and "seconds_all_gather_assemble" in stats)
+    comm.close()
+    out.put((ok, "torch" in sys.modules))
 
 
-def test_compare_matrix_all_gather_on_device_memory():
-    """The RCCL leg of the N > 1 path on the one GPU a test box has: a group of one rank over the "nccl" backend,
-    the collective forced on.  RCCL reads the label block at the address the library hands out
-    (malcs_relmatrix_tiles_device) and the assembly kernel reads what RCCL wrote (malcs_relmatrix_assemble_device)."""
-    import torch.multiprocessing as mp
+def test_compare_matrix_all_gather_over_rccl():
+    """The RCCL leg of the N > 1 path on the one GPU a test box has: a job of one rank, the library's own
+    communicator (librccl bound at run time, algebra_amd/comm.py for the id), ncclAllGather from the buffer the tile
+    kernels wrote into the buffer the assembly kernel reads (malcs_relmatrix_assemble_comm).  No torch in the process."""
+    import multiprocessing as mp
     ctx = mp.get_context("spawn")
     out = ctx.Queue()
     port = 33500 + np.random.RandomState().randint(0, 2000)
     proc = ctx.Process(target=_matrix_rccl_rank, args=(port, out))
     proc.start()
-    ok = out.get(timeout=150)
+    ok, torch_loaded = out.get(timeout=150)
     proc.join(timeout=60)
     assert proc.exitcode == 0
     assert ok and all(ok)
+    assert not torch_loaded
 
 
 def test_compare_matrix_c4_full_size():

@@ -109,7 +109,9 @@ def _rank_main(rank, world, port, out):
         from algebra_amd.relations import compare_matrix
         case = SEQS["matrices"][0]
         stats = {}
-        labels = compare_matrix(case["reference"], matrix_inputs(case), tile=8, distance_fn=oracle_distances, stats=stats, tiles_cls=HostTiles)
+        from util import gloo_gather
+        labels = compare_matrix(case["reference"], matrix_inputs(case), tile=8, rank=rank, world=world, gather=gloo_gather(dist),
+                                distance_fn=oracle_distances, stats=stats, tiles_cls=HostTiles)
         out.put((rank, labels.tolist() == case["labels"], stats["tiles"]))
     finally:
         dist.destroy_process_group()

@@ -142,3 +142,17 @@ class HostTiles:
 
     def close(self):
         pass
+
+
+def gloo_gather(dist):
+    """`gather` for compare_matrix over an initialised torch.distributed group (TEST INFRASTRUCTURE: the product's own
+    collective is RCCL inside the library; gloo lets two ranks meet on a CPU or on one GPU)."""
+    import numpy as np
+    import torch
+
+    def gather(block):
+        send = torch.from_numpy(np.ascontiguousarray(block))
+        recv = torch.empty((dist.get_world_size() * block.shape[0],) + tuple(block.shape[1:]), dtype=torch.uint8)
+        dist.all_gather_into_tensor(recv, send)
+        return recv.numpy()
+    return gather
