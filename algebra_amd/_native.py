@@ -159,6 +159,39 @@ def default_context():
     return _default_ctx
 
 
+_device_contexts = {}
+
+
+def contexts_for(devices=None):
+    """One context per entry of `devices` (a device may be named twice: two contexts, two streams); None without a
+    device list (argument or MALCS_DEVICES=0,1,...): the caller then uses the process's default context."""
+    if devices is None:
+        env = os.environ.get("MALCS_DEVICES", "")
+        if not env.strip():
+            return None
+        devices = [int(x) for x in env.split(",") if x.strip()]
+    out = []
+    for slot, device in enumerate(devices):
+        key = (slot, int(device))
+        ctx = _device_contexts.get(key)
+        if ctx is None or not ctx.handle:
+            ctx = _device_contexts[key] = Context(int(device))
+        out.append(ctx)
+    return out
+
+
+def run_on_devices(fn, jobs):
+    """fn(job) for every job, one host thread each (the library releases the GIL inside its calls and binds the
+    thread to the job's device); the first exception is re-raised after all have finished."""
+    from concurrent.futures import ThreadPoolExecutor
+    with ThreadPoolExecutor(max_workers=max(1, len(jobs))) as pool:
+        futures = [pool.submit(fn, job) for job in jobs]
+        errors = [f.exception() for f in futures]
+    for e in errors:
+        if e is not None:
+            raise e
+
+
 class Batch:
     """Sequence pairs resident in HBM (malcs_batch)."""
 

@@ -20,6 +20,46 @@ def _raw(seq):
         return np.frombuffer(seq.encode("utf-32-le"), dtype=np.uint32)
 
 
+class TooManySymbols(ValueError):
+    """More distinct symbols than the device's 8 bit planes hold, even after reducing every pair to the symbols its
+    two sequences share.  Batch callers split the batch and try again; for a single pair it is final."""
+
+
+def _encode_shared_only(pairs):
+    """The batch has more than 256 distinct symbols.  Only equality between a symbol of `a` and a symbol of `b`
+    of the same pair matters (reference edit_distance.py:26, lcs_graph.py:287), so a symbol that occurs on one side
+    only of every pair it is in needs no code of its own: all such symbols of an `a` get one code, those of a `b`
+    another.  Sequences are not shared between pairs here (one stored sequence could otherwise serve as `a` and as
+    `b`)."""
+    pairs = [tuple(pair) for pair in pairs]
+    shared = set()
+    for a, b in pairs:
+        shared |= set(a) & set(b)
+    if len(shared) + 2 > _MAX_SYMBOLS:
+        raise TooManySymbols(f"{len(shared)} distinct symbols are shared inside the pairs of one batch; libmalcs packs at most "
+                             f"{_MAX_SYMBOLS - 2} of them")
+    table = {sym: code for code, sym in enumerate(sorted(shared, key=repr))}
+    only_a, only_b = len(table), len(table) + 1
+    chunks, lens = [], []
+    for a, b in pairs:
+        chunks.append(np.fromiter((table.get(x, only_a) for x in a), dtype=np.uint8, count=len(a)))
+        chunks.append(np.fromiter((table.get(x, only_b) for x in b), dtype=np.uint8, count=len(b)))
+        lens += [len(a), len(b)]
+    lens = np.array(lens, dtype=np.uint64).reshape(-1, 2)
+    offs = np.concatenate([[0], np.cumsum(lens.reshape(-1))[:-1]]).astype(np.uint64).reshape(-1, 2)
+    syms = np.concatenate(chunks + [np.zeros(1, np.uint8)])
+    return (syms, np.ascontiguousarray(offs[:, 0]), np.ascontiguousarray(lens[:, 0]).astype(np.uint32),
+            np.ascontiguousarray(offs[:, 1]), np.ascontiguousarray(lens[:, 1]).astype(np.uint32), len(table) + 2)
+
+
+def deal(pairs, n_parts):
+    """Indices of `pairs` for each of `n_parts` devices: pairs sorted by the 64-row word count of their
+    shorter sequence, dealt round-robin, so that every device gets the same mix of launch classes."""
+    words = np.fromiter(((min(len(a), len(b)) + 63) // 64 for a, b in pairs), dtype=np.int64, count=len(pairs))
+    order = np.argsort(words, kind="stable")
+    return [order[k::n_parts] for k in range(n_parts)]
+
+
 def encode_pairs(pairs):
     """[(reference, observed), ...] -> (syms, a_off, a_len, b_off, b_len, n_symbols).
 
@@ -57,7 +97,7 @@ def encode_pairs(pairs):
     dna = [ord(ch) for ch in "ACGT"]
     others = [int(v) for v in present if int(v) not in dna]
     if len(others) + 4 > _MAX_SYMBOLS and len(present) > _MAX_SYMBOLS:
-        raise ValueError(f"{len(present)} distinct symbols in one batch; libmalcs packs at most {_MAX_SYMBOLS}")
+        return _encode_shared_only(pairs)
     table = {v: i for i, v in enumerate(dna)}
     for v in others:
         table[v] = len(table)

@@ -15,7 +15,7 @@ import numpy as np
 
 from .. import _native
 from ..variants import Variant, patch
-from .encoding import encode_pairs
+from .encoding import TooManySymbols, deal, encode_pairs
 
 
 class LCSgraph:
@@ -103,8 +103,9 @@ class LCSgraph:
         return result.canonical(index)
 
     @classmethod
-    def batch(cls, pairs, shifts=None, max_distances=None, ctx=None):
-        """`[LCSgraph(reference, observed, shift, max_distance), ...]` in one device batch.
+    def batch(cls, pairs, shifts=None, max_distances=None, ctx=None, devices=None):
+        """`[LCSgraph(reference, observed, shift, max_distance), ...]` in one device batch, or, with `devices`
+        (a list of device ids; default MALCS_DEVICES when set), dealt over one context per entry.
 
         Raises ValueError("maximum distance exceeded") if any pair exceeds its limit
         (reference lcs_graph.py:345-346)."""
@@ -112,12 +113,33 @@ class LCSgraph:
         n = len(pairs)
         if n == 0:
             return []
-        ctx = ctx or _native.default_context()
-        syms, a_off, a_len, b_off, b_len, n_symbols = encode_pairs(pairs)
         shift = np.zeros(n, dtype=np.int64) if shifts is None else np.asarray(list(shifts), dtype=np.int64)
         limit = None
         if max_distances is not None:
             limit = np.array([int(x) if x else 0 for x in max_distances], dtype=np.int64)
+        contexts = _native.contexts_for(devices) if ctx is None else None
+        if contexts and len(contexts) > 1 and n > 1:
+            out = [None] * n
+
+            def part(job):
+                context, index = job
+                index = index.tolist()
+                if not index:
+                    return
+                built = cls.batch([pairs[i] for i in index], shift[index], None if limit is None else limit[index], ctx=context)
+                for i, graph in zip(index, built):
+                    out[i] = graph
+            _native.run_on_devices(part, list(zip(contexts, deal(pairs, len(contexts)))))
+            return out
+        ctx = ctx or (contexts[0] if contexts else _native.default_context())
+        try:
+            syms, a_off, a_len, b_off, b_len, n_symbols = encode_pairs(pairs)
+        except TooManySymbols:
+            if n < 2:
+                raise
+            half = n // 2
+            return (cls.batch(pairs[:half], shift[:half], None if limit is None else limit[:half], ctx=ctx) +
+                    cls.batch(pairs[half:], shift[half:], None if limit is None else limit[half:], ctx=ctx))
         batch = _native.Batch(ctx, syms, a_off, a_len, b_off, b_len, n_symbols)
         try:
             res = batch.graphs(shift, limit)

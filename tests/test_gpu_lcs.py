@@ -646,3 +646,47 @@ def test_c5_ii_one_megabase_two_percent(native, path, monkeypatch):
         assert "".join(pieces + [a[pos:]]) == b and cost >= want
     finally:
         res.close()
+
+
+def test_more_than_256_symbols(native):
+    """Arbitrary str code points (reference edit_distance.py:26): a batch with hundreds of distinct symbols goes to the
+    device with one code per symbol a pair's two sides share, and splits when even that is too many."""
+    import algebra_amd
+    from algebra_amd.lcs import LCSgraph
+    from oracle import py_oracle as P
+    rs = np.random.RandomState(41)
+    pairs = []
+    for k in range(40):
+        alphabet = [chr(0x400 + 40 * k + i) for i in range(40)]          # 1 600 distinct symbols in the batch
+        a = "".join(rs.choice(alphabet, 120))
+        b = "".join(ch for ch in a if rs.random_sample() > 0.1) + "".join(rs.choice(alphabet, 5))
+        pairs.append((a, b))
+    want = [P.edit_distance(a, b) for a, b in pairs]
+    assert algebra_amd.edit_distance_batch(pairs).tolist() == want
+    graphs = LCSgraph.batch(pairs[:12])
+    assert [g.distance for g in graphs] == want[:12]
+    for (a, b), g in zip(pairs[:12], graphs):
+        v = g.supremal
+        assert a[:v.start] + v.sequence + a[v.end:] == b
+
+
+def test_pairs_dealt_over_two_contexts(native):
+    """The multi-device entry of the facade: pairs dealt over one context per listed device, results in
+    the caller's order.  A test box has one GPU: the two contexts sit on device 0."""
+    import algebra_amd
+    from algebra_amd.lcs import LCSgraph
+    from algebra_amd.lcs.encoding import deal
+    from util import graph_record
+    rs = np.random.RandomState(43)
+    pairs = []
+    for m in list(rs.randint(0, 3000, 300)) + [5000, 0, 64, 65]:
+        a = gen.random_seq(rs, int(m))
+        pairs.append((a, gen.mutate(rs, a, 0.02, 0.02)))
+    parts = deal(pairs, 2)
+    assert sorted(np.concatenate(parts).tolist()) == list(range(len(pairs))) and abs(len(parts[0]) - len(parts[1])) <= 1
+    one = algebra_amd.edit_distance_batch(pairs)
+    two = algebra_amd.edit_distance_batch(pairs, devices=[0, 0])
+    assert np.array_equal(one, two)
+    g1 = LCSgraph.batch(pairs[:60], shifts=range(60))
+    g2 = LCSgraph.batch(pairs[:60], shifts=range(60), devices=[0, 0])
+    assert [graph_record(g) for g in g1] == [graph_record(g) for g in g2]

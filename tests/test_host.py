@@ -112,5 +112,15 @@ def test_encoding():
     assert n == 7 and len(set(syms[:6].tolist())) == 4 and syms[1] == syms[5] and syms[2] == syms[3]
     syms, *_, n = encode_pairs([("", "")])
     assert n == 4
-    with pytest.raises(ValueError):
-        encode_pairs([("".join(chr(300 + i) for i in range(300)), "A")])
+    # more than 256 distinct symbols in a batch: only the symbols the two sides of a pair share need codes of their own
+    # (equality is all the reference looks at, edit_distance.py:26); the rest get one code per side
+    wide_a = "".join(chr(300 + i) for i in range(300))
+    syms, a_off, a_len, b_off, b_len, n = encode_pairs([(wide_a, "A" + wide_a[5:9] + "B"), ("XY", "YZ")])
+    assert n == 7                                             # 4 shared in pair 0, 1 in pair 1, + one code per side
+    a0 = syms[int(a_off[0]):int(a_off[0]) + 300]
+    b0 = syms[int(b_off[0]):int(b_off[0]) + 6]
+    assert (a0[5:9] == b0[1:5]).all() and len(set(a0[5:9].tolist())) == 4
+    assert set(np.delete(a0, [5, 6, 7, 8]).tolist()) == {5} and b0[0] == b0[5] == 6
+    from algebra_amd.lcs.encoding import TooManySymbols
+    with pytest.raises(TooManySymbols):
+        encode_pairs([(wide_a, wide_a[::-1])])                # 300 shared symbols in one pair: nothing left to fold
