@@ -91,6 +91,7 @@ MALCS_HD void build(arena &A, int32_t m, int32_t n, int64_t shift, const int32_t
     // only two lists are alive at a time (the level being emptied and the one below it) -- the reference's list of
     // ~LLCS lists would cost an allocation per level.
     for (int32_t r = 0; r < n_runs; r++) add_node(A, runs[4 * r], runs[4 * r + 1], runs[4 * r + 2]);
+    if (A.overflow || A.list_cap < 1) { A.overflow = 1; return; }         // node id == run index needs every run in the arena
     int32_t unread = n_runs;                                             // runs [0, unread) are not in a list yet
     const int32_t last = n_runs - 1;                                     // last node of the last level, :379-385
     if (A.row[last] + A.length[last] == m && A.col[last] + A.length[last] == n) {
@@ -162,6 +163,7 @@ MALCS_HD void build(arena &A, int32_t m, int32_t n, int64_t shift, const int32_t
         n_cur = n_below;
     }
 
+    if (A.overflow) return;
     int32_t first = 0;                                                   // level 0, :428-432
     source = n_cur ? cur[0] : sink;
     if (n_cur && A.row[source] == 0 && A.col[source] == 0) first = 1;

@@ -64,3 +64,17 @@ def test_build_graph_rejects_bad_runs():
         _native.graphs_from_runs([4], [4], [0], [2], [[0, 0, 5, 0]], [0, 1])      # run longer than the sequences
     with pytest.raises(_native.MalcsError):
         _native.graphs_from_runs([4], [4], [0], [2], [[0, 0, 1, 1], [1, 1, 1, 0]], [0, 2])   # levels descending
+
+
+def test_sanitizer_run_of_host_graph_code():
+    """`make -C oracle asan`: the oracle and the library's graph construction (malcs_graph_core.hpp, arena overflow
+    paths included) under AddressSanitizer + UBSan on seeded pairs, compared with each other (tests/checks/asan_core.cpp)."""
+    import os
+    import shutil
+    import subprocess
+    if not shutil.which("g++") or not shutil.which("make"):
+        pytest.skip("no g++ / make")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    done = subprocess.run(["make", "-C", os.path.join(root, "oracle"), "asan"], capture_output=True, text=True, timeout=600)
+    assert done.returncode == 0, done.stdout[-2000:] + done.stderr[-2000:]
+    assert "0 mismatches" in done.stdout
