@@ -71,6 +71,8 @@ def _load():
         "malcs_relmatrix_pending_count": (c.c_int, [vp, P(u64)]),
         "malcs_relmatrix_pending": (c.c_int, [vp, vp]),
         "malcs_relmatrix_resolve": (c.c_int, [vp, vp]),
+        "malcs_relmatrix_decide": (c.c_int, [vp, vp, u64, vp, vp, vp, vp, vp, c.c_int, P(u64)]),
+        "malcs_graphs_atoms": (c.c_int, [vp, u64, vp, vp, vp, vp, vp]),
         "malcs_relmatrix_tiles": (c.c_int, [vp, vp]),
         "malcs_relmatrix_assemble": (c.c_int, [vp, vp, vp]),
         "malcs_relmatrix_tiles_device": (c.c_int, [vp, P(vp), P(u64)]),
@@ -313,6 +315,12 @@ class Graphs:
         check(lib.malcs_graphs_edges(self.handle, i, ptr(out)))
         return out
 
+    def atoms(self, index, obs, obs_off, out_range, out):
+        """Atom masks of the graphs `index` of this handle into out[out_range[k, 0]:out_range[k, 1]] (malcs_graphs_atoms)."""
+        index = np.ascontiguousarray(index, dtype=np.uint64)
+        out_range = np.ascontiguousarray(out_range, dtype=np.uint64)
+        check(lib.malcs_graphs_atoms(self.handle, len(index), ptr(index), ptr(obs), ptr(obs_off), ptr(out_range), ptr(out)))
+
     def canonical(self, i):
         n = ctypes.c_int64()
         check(lib.malcs_graphs_canonical_count(self.handle, i, ctypes.byref(n)))
@@ -404,6 +412,17 @@ class RelationMatrix:
         pairs = np.zeros((count.value, 2), dtype=np.int64)
         check(lib.malcs_relmatrix_pending(self.handle, ptr(pairs)))
         return pairs
+
+    def decide(self, ref, sup, sup_off, distance, atoms, atom_off, n_symbols):
+        """The undecided pairs decided on the device (union windows, distances, distance arithmetic, atom masks);
+        returns how many pairs reached the DP."""
+        n_dp = ctypes.c_uint64()
+        keep = [np.ascontiguousarray(ref, dtype=np.uint8), np.ascontiguousarray(sup, dtype=np.uint8),
+                np.ascontiguousarray(sup_off, dtype=np.uint64), np.ascontiguousarray(distance, dtype=np.int64),
+                np.ascontiguousarray(atoms, dtype=np.uint8), np.ascontiguousarray(atom_off, dtype=np.uint64)]
+        check(lib.malcs_relmatrix_decide(self.handle, ptr(keep[0]), keep[0].size, ptr(keep[1]), ptr(keep[2]), ptr(keep[3]), ptr(keep[4]),
+                                         ptr(keep[5]), int(n_symbols), ctypes.byref(n_dp)))
+        return n_dp.value
 
     def resolve(self, codes):
         codes = np.ascontiguousarray(codes, dtype=np.uint8)

@@ -315,7 +315,9 @@ static bool sequences_apart(const uint64_t *a_off, const uint32_t *a_len, const 
     return interleaved || (blocks && (a_end <= b_min || b_end <= a_min));
 }
 
-static int batch_build(malcs_ctx *ctx, const uint8_t *syms, uint64_t n_syms,
+// `syms`: the caller's symbols in host memory -- or, with `d_syms`, already in device memory (callers inside the library
+// that put sequences together on the device: the relation matrix's union windows), then packed there by k_pack_planes
+static int batch_build(malcs_ctx *ctx, const uint8_t *syms, const uint8_t *d_syms, uint64_t n_syms,
                        const uint64_t *a_off, const uint32_t *a_len, const uint64_t *b_off, const uint32_t *b_len,
                        uint64_t n_pairs, int n_symbols, malcs_batch *b)
 {
@@ -406,7 +408,17 @@ static int batch_build(malcs_ctx *ctx, const uint8_t *syms, uint64_t n_syms,
         MALCS_HIP(malcs_h2d(st, b->d_a_len, b->a_len.data(), n_pairs * 4));
         MALCS_HIP(malcs_h2d(st, b->d_b_off, b->b_off.data(), n_pairs * 4));
         MALCS_HIP(malcs_h2d(st, b->d_b_len, b->b_len.data(), n_pairs * 4));
-        if (total_blocks) {
+        if (total_blocks && d_syms) {
+            pool_scoped<uint64_t> d_sbo(ctx);
+            pool_scoped<uint32_t> d_sl(ctx), d_sko(ctx);
+            MALCS_HIP(d_sbo.alloc(n_seqs)); MALCS_HIP(d_sl.alloc(n_seqs)); MALCS_HIP(d_sko.alloc(n_seqs));
+            MALCS_HIP(malcs_h2d(st, d_sbo.p, seq_byte_off.data(), (size_t)n_seqs * 8));
+            MALCS_HIP(malcs_h2d(st, d_sl.p, seq_len.data(), (size_t)n_seqs * 4));
+            MALCS_HIP(malcs_h2d(st, d_sko.p, seq_blk_off.data(), (size_t)n_seqs * 4));
+            const int rc = malcs_pack_launch(ctx, d_syms, d_sbo.p, d_sl.p, d_sko.p, n_seqs, (uint32_t)total_blocks, b->n_planes, b->d_planes);
+            if (rc) return rc;
+            if ((size_t)n_seqs * 8 > (1u << 20)) MALCS_HIP(malcs_sync(st));     // copies beyond the staging buffer read the vectors directly
+        } else if (total_blocks) {
             // the planes are packed here, on the host's cores, into pinned memory, and cross PCIe packed; every stretch
             // the packers finish is queued for its copy at once
             const size_t arena_bytes = (size_t)b->arena_dwords * sizeof(uint32_t);
@@ -467,7 +479,7 @@ int malcs_batch_create(malcs_ctx *ctx, const uint8_t *syms, uint64_t n_syms,
     if (!ctx->spare_batches.empty()) { b = ctx->spare_batches.back(); ctx->spare_batches.pop_back(); }
     else b = new (std::nothrow) malcs_batch();
     if (!b) { malcs_set_error("out of host memory"); return MALCS_ERR_NOMEM; }
-    int rc = batch_build(ctx, syms, n_syms, a_off, a_len, b_off, b_len, n_pairs, n_symbols, b);
+    int rc = batch_build(ctx, syms, nullptr, n_syms, a_off, a_len, b_off, b_len, n_pairs, n_symbols, b);
     if (rc) {
         (void)hipStreamSynchronize(ctx->stream);                 // copies out of the context's pinned buffers may be in flight
         batch_release(b);
@@ -476,6 +488,25 @@ int malcs_batch_create(malcs_ctx *ctx, const uint8_t *syms, uint64_t n_syms,
     *out = b;
     return MALCS_OK;
 }
+
+}  // extern "C"
+
+int malcs_batch_create_device(malcs_ctx *ctx, const uint8_t *d_syms, uint64_t n_syms,
+                              const uint64_t *a_off, const uint32_t *a_len, const uint64_t *b_off, const uint32_t *b_len,
+                              uint64_t n_pairs, int n_symbols, malcs_batch **out)
+{
+    *out = nullptr;
+    malcs_batch *b = nullptr;
+    if (!ctx->spare_batches.empty()) { b = ctx->spare_batches.back(); ctx->spare_batches.pop_back(); }
+    else b = new (std::nothrow) malcs_batch();
+    if (!b) { malcs_set_error("out of host memory"); return MALCS_ERR_NOMEM; }
+    const int rc = batch_build(ctx, nullptr, d_syms, n_syms, a_off, a_len, b_off, b_len, n_pairs, n_symbols, b);
+    if (rc) { (void)hipStreamSynchronize(ctx->stream); batch_release(b); return rc; }
+    *out = b;
+    return MALCS_OK;
+}
+
+extern "C" {
 
 int malcs_batch_destroy(malcs_batch *b)
 {

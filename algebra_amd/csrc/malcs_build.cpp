@@ -1012,6 +1012,48 @@ int malcs_graphs_canonical(malcs_graphs *g, uint64_t i, int64_t *dst)
     return MALCS_OK;
 }
 
+int malcs_graphs_atoms(malcs_graphs *g, uint64_t count, const uint64_t *index, const uint8_t *obs, const uint64_t *obs_off,
+                       const uint64_t *out_range, uint8_t *out)
+{
+    if (!g || (count && (!index || !obs_off || !out_range || !out))) { malcs_set_error("NULL argument"); return MALCS_ERR_ARG; }
+    std::vector<int32_t> diff;
+    for (uint64_t k = 0; k < count; k++) {
+        if (index[k] >= g->g.size() || g->g[index[k]].status != MALCS_PAIR_OK) { malcs_set_error("pair %llu has no graph", (unsigned long long)index[k]); return MALCS_ERR_ARG; }
+        pair_graph &G = g->g[index[k]];
+        widen(g, G);
+        const int64_t lo = G.supremal[0], size = G.supremal[1] - lo + 1;
+        if (size < 1 || (uint64_t)size != out_range[2 * k + 1] - out_range[2 * k]) {
+            malcs_set_error("pair %llu: the supremal spans %lld positions, the caller left room for %llu", (unsigned long long)index[k],
+                            (long long)size, (unsigned long long)(out_range[2 * k + 1] - out_range[2 * k]));
+            return MALCS_ERR_ARG;
+        }
+        const uint8_t *o = obs ? obs + obs_off[k] : nullptr;
+        const int64_t n_obs = (int64_t)(obs_off[k + 1] - obs_off[k]);
+        diff.assign((size_t)(5 * (size + 2)), 0);
+        const size_t ne = G.edges.size() / 6;
+        for (size_t e = 0; e < ne; e++) {
+            const int64_t *x = &G.edges[6 * e];
+            const int64_t s = x[2] - lo, t = x[3] - lo;
+            if (s < 0 || t < s || t >= size || x[4] < 0 || x[5] < x[4] || x[5] > n_obs) { malcs_set_error("pair %llu: edge outside its supremal or its observed sequence", (unsigned long long)index[k]); return MALCS_ERR_ARG; }
+            diff[(size_t)s] += 1; diff[(size_t)t] -= 1;                                         // (idx, "") for idx in [start, end)
+            uint32_t present = 0;
+            for (int64_t q = x[4]; q < x[5] && present != 15u; q++) {
+                if (o[q] > 3) { malcs_set_error("pair %llu: symbol code %u in the observed sequence (atom masks are for codes 0 ... 3)", (unsigned long long)index[k], o[q]); return MALCS_ERR_ARG; }
+                present |= 1u << o[q];
+            }
+            for (int c = 0; c < 4; c++) if (present >> c & 1u) { diff[(size_t)((c + 1) * (size + 2) + s)] += 1; diff[(size_t)((c + 1) * (size + 2) + t + 1)] -= 1; }   // (idx, ch) for idx in [start, end]
+        }
+        uint8_t *m = out + out_range[2 * k];
+        int32_t run[5] = {0, 0, 0, 0, 0};
+        for (int64_t q = 0; q < size; q++) {
+            uint8_t v = 0;
+            for (int c = 0; c < 5; c++) { run[c] += diff[(size_t)(c * (size + 2) + q)]; if (run[c] > 0) v |= (uint8_t)(1u << c); }
+            m[q] = v;
+        }
+    }
+    return MALCS_OK;
+}
+
 int malcs_graphs_device_built(const malcs_graphs *g, uint64_t *count, float *ms)
 {
     if (!g) { malcs_set_error("NULL argument"); return MALCS_ERR_ARG; }

@@ -188,6 +188,11 @@ struct malcs_batch {
     uint32_t max_len = 0;
 };
 
+// malcs_api.cpp: a batch whose symbols (one byte each) already sit in device memory; offsets and lengths on the host
+int malcs_batch_create_device(malcs_ctx *ctx, const uint8_t *d_syms, uint64_t n_syms,
+                              const uint64_t *a_off, const uint32_t *a_len, const uint64_t *b_off, const uint32_t *b_len,
+                              uint64_t n_pairs, int n_symbols, malcs_batch **out);
+
 // malcs_noalloc.hip
 int malcs_noalloc_setup(malcs_ctx *c);
 

@@ -94,6 +94,68 @@ k_relation_assemble(uint32_t n, uint32_t tile, uint32_t blocks, uint32_t world, 
     full[(size_t)i * n + j] = v;
 }
 
+// ---- the undecided pairs, decided on the device ----------------------------------------------------------
+// pending cell k -> its variants (i, j) and the lengths of its two union-window sequences (graph_based.py:57-64):
+// window [min(start), max(end)), each side = reference up to its supremal + the supremal's sequence + reference after it
+__global__ void __launch_bounds__(256)
+k_relation_window_lens(const uint64_t *__restrict__ cells, uint64_t count, uint32_t tile, uint32_t blocks, uint32_t rank, uint32_t world,
+                       const int64_t *__restrict__ start, const int64_t *__restrict__ end, const uint64_t *__restrict__ sup_off,
+                       uint32_t *__restrict__ ij, uint32_t *__restrict__ lens)
+{
+    const uint64_t k = (uint64_t)blockIdx.x * 256u + threadIdx.x;
+    if (k >= count) return;
+    const uint64_t tile_cells = (uint64_t)tile * tile, cell = cells[k], t = cell / tile_cells, in = cell % tile_cells;
+    uint32_t bi, bj;
+    tile_coords((uint32_t)(t * world + rank), blocks, bi, bj);
+    const uint32_t i = bi * tile + (uint32_t)(in / tile), j = bj * tile + (uint32_t)(in % tile);
+    ij[2 * k] = i; ij[2 * k + 1] = j;
+    const int64_t ws = min(start[i], start[j]), we = max(end[i], end[j]);
+    lens[2 * k] = (uint32_t)((start[i] - ws) + (int64_t)(sup_off[i + 1] - sup_off[i]) + (we - end[i]));
+    lens[2 * k + 1] = (uint32_t)((start[j] - ws) + (int64_t)(sup_off[j + 1] - sup_off[j]) + (we - end[j]));
+}
+
+// one workgroup of 64 per window sequence (2 k: the side of variant i, 2 k + 1: of variant j)
+__global__ void __launch_bounds__(64)
+k_relation_window_fill(const uint32_t *__restrict__ ij, const int64_t *__restrict__ start, const int64_t *__restrict__ end,
+                       const uint8_t *__restrict__ ref, const uint8_t *__restrict__ sup, const uint64_t *__restrict__ sup_off,
+                       const uint64_t *__restrict__ out_off, uint8_t *__restrict__ out)
+{
+    const uint64_t q = blockIdx.x, k = q >> 1;
+    const uint32_t i = ij[2 * k], j = ij[2 * k + 1], v = (q & 1) ? j : i;
+    const int64_t ws = min(start[i], start[j]), we = max(end[i], end[j]);
+    const int64_t pre = start[v] - ws, mid = (int64_t)(sup_off[v + 1] - sup_off[v]), post = we - end[v];
+    uint8_t *o = out + out_off[q];
+    for (int64_t p = threadIdx.x; p < pre + mid + post; p += 64)
+        o[p] = p < pre ? ref[ws + p] : (p < pre + mid ? sup[sup_off[v] + (uint64_t)(p - pre)] : ref[end[v] + (p - pre - mid)]);
+}
+
+// :67-79 for pending pair k: the three distances, then the atom masks; the verdict goes straight into the label tile
+__global__ void __launch_bounds__(256)
+k_relation_verdict(const uint64_t *__restrict__ cells, const uint32_t *__restrict__ ij, uint64_t count, const int32_t *__restrict__ dist,
+                   const int64_t *__restrict__ distance, const int64_t *__restrict__ start, const uint8_t *__restrict__ atoms,
+                   const uint64_t *__restrict__ atom_off, uint8_t *__restrict__ labels)
+{
+    const uint64_t k = (uint64_t)blockIdx.x * 256u + threadIdx.x;
+    if (k >= count) return;
+    const uint32_t i = ij[2 * k], j = ij[2 * k + 1];
+    const int64_t li = distance[i], rj = distance[j], d = dist[k];
+    uint8_t code;
+    if (li + rj == d) code = DISJOINT;
+    else if (li - rj == d) code = CONTAINS;
+    else if (rj - li == d) code = IS_CONTAINED;
+    else {
+        // LCSgraph.is_disjoint: no atom in common at any position both graphs have atoms for
+        const int64_t lo_i = start[i], lo_j = start[j];
+        const int64_t n_i = (int64_t)(atom_off[i + 1] - atom_off[i]), n_j = (int64_t)(atom_off[j + 1] - atom_off[j]);
+        const int64_t lo = max(lo_i, lo_j), hi = min(lo_i + n_i, lo_j + n_j);
+        const uint8_t *a = atoms + atom_off[i] + (lo - lo_i), *b = atoms + atom_off[j] + (lo - lo_j);
+        uint8_t any = 0;
+        for (int64_t p = 0; p < hi - lo; p++) any |= a[p] & b[p];
+        code = any ? (uint8_t)3 : DISJOINT;                          // 3 = OVERLAP
+    }
+    labels[cells[k]] = code;
+}
+
 template <typename T> struct dev {
     T *p = nullptr;
     ~dev() { if (p) hipFree(p); }
@@ -107,6 +169,7 @@ struct malcs_relmatrix {
     uint32_t n = 0, tile = 0, blocks = 0, rank = 0, world = 1, n_tiles = 0, mine = 0, per_rank = 0;
     dev<uint8_t> labels;               // this rank's tiles, per_rank x tile x tile (unused slots zero)
     dev<uint64_t> cells;               // undecided cells (index into labels)
+    dev<int64_t> start, end;           // the variants' intervals (kept for malcs_relmatrix_decide)
     uint64_t n_pending = 0;
     std::vector<uint64_t> host_cells;
 };
@@ -135,7 +198,7 @@ int malcs_relmatrix_create(malcs_ctx *ctx, uint64_t n, const int64_t *start, con
     h->mine = h->n_tiles > rank ? (h->n_tiles - rank + world - 1) / world : 0;
     h->per_rank = (h->n_tiles + world - 1) / world;
     const size_t tile_cells = (size_t)tile * tile, n_cells = (size_t)h->per_rank * tile_cells;
-    dev<int64_t> d_start, d_end;
+    dev<int64_t> &d_start = h->start, &d_end = h->end;
     dev<uint32_t> d_key;
     dev<uint64_t> d_mask;
     dev<unsigned long long> d_count;
@@ -218,6 +281,64 @@ int malcs_relmatrix_resolve(malcs_relmatrix *h, const uint8_t *codes)
     MALCS_HIP(hipGetLastError());
     MALCS_HIP(malcs_sync(st));
     return MALCS_OK;
+}
+
+int malcs_relmatrix_decide(malcs_relmatrix *h, const uint8_t *ref, uint64_t ref_len, const uint8_t *sup, const uint64_t *sup_off,
+                           const int64_t *distance, const uint8_t *atoms, const uint64_t *atom_off, int n_symbols, uint64_t *n_dp)
+{
+    if (!h || !sup_off || !distance || !atom_off || (ref_len && !ref)) { malcs_set_error("NULL argument"); return MALCS_ERR_ARG; }
+    if (n_dp) *n_dp = h->n_pending;
+    if (!h->n_pending) return MALCS_OK;
+    malcs_ctx *ctx = h->ctx;
+    MALCS_HIP(hipSetDevice(ctx->device));
+    hipStream_t st = ctx->stream;
+    const uint64_t count = h->n_pending, n = h->n;
+    if (sup_off[n] && !sup) { malcs_set_error("NULL argument"); return MALCS_ERR_ARG; }
+    if (atom_off[n] && !atoms) { malcs_set_error("NULL argument"); return MALCS_ERR_ARG; }
+    pool_scoped<uint8_t> d_ref(ctx), d_sup(ctx), d_atoms(ctx), d_syms(ctx);
+    pool_scoped<uint64_t> d_sup_off(ctx), d_atom_off(ctx), d_out_off(ctx);
+    pool_scoped<int64_t> d_distance(ctx);
+    pool_scoped<uint32_t> d_ij(ctx), d_lens(ctx);
+    MALCS_HIP(d_ref.alloc(ref_len + 1)); MALCS_HIP(d_sup.alloc(sup_off[n] + 1)); MALCS_HIP(d_atoms.alloc(atom_off[n] + 1));
+    MALCS_HIP(d_sup_off.alloc(n + 1)); MALCS_HIP(d_atom_off.alloc(n + 1)); MALCS_HIP(d_distance.alloc(n));
+    MALCS_HIP(d_ij.alloc(2 * count)); MALCS_HIP(d_lens.alloc(2 * count)); MALCS_HIP(d_out_off.alloc(2 * count));
+    if (ref_len) MALCS_HIP(malcs_h2d(st, d_ref.p, ref, ref_len));
+    if (sup_off[n]) MALCS_HIP(malcs_h2d(st, d_sup.p, sup, sup_off[n]));
+    if (atom_off[n]) MALCS_HIP(malcs_h2d(st, d_atoms.p, atoms, atom_off[n]));
+    MALCS_HIP(malcs_h2d(st, d_sup_off.p, sup_off, (n + 1) * 8));
+    MALCS_HIP(malcs_h2d(st, d_atom_off.p, atom_off, (n + 1) * 8));
+    MALCS_HIP(malcs_h2d(st, d_distance.p, distance, n * 8));
+    const dim3 grid((uint32_t)((count + 255) / 256)), b256(256);
+    hipLaunchKernelGGL(k_relation_window_lens, grid, b256, 0, st, h->cells.p, count, h->tile, h->blocks, h->rank, h->world, h->start.p, h->end.p,
+                       d_sup_off.p, d_ij.p, d_lens.p);
+    MALCS_HIP(hipGetLastError());
+    std::vector<uint32_t> lens(2 * count);
+    MALCS_HIP(malcs_d2h(st, lens.data(), d_lens.p, 2 * count * sizeof(uint32_t)));
+    MALCS_HIP(malcs_sync(st));
+    // the windows back to back: pair k's two sequences at off[2 k], off[2 k + 1]
+    std::vector<uint64_t> off(2 * count);
+    std::vector<uint64_t> a_off(count), b_off(count);
+    std::vector<uint32_t> a_len(count), b_len(count);
+    uint64_t total = 0;
+    for (uint64_t q = 0; q < 2 * count; q++) { off[q] = total; total += lens[q]; }
+    for (uint64_t k = 0; k < count; k++) { a_off[k] = off[2 * k]; a_len[k] = lens[2 * k]; b_off[k] = off[2 * k + 1]; b_len[k] = lens[2 * k + 1]; }
+    MALCS_HIP(d_syms.alloc(total + 1));
+    MALCS_HIP(malcs_h2d(st, d_out_off.p, off.data(), 2 * count * 8));
+    hipLaunchKernelGGL(k_relation_window_fill, dim3((uint32_t)(2 * count)), dim3(64), 0, st, d_ij.p, h->start.p, h->end.p, d_ref.p, d_sup.p,
+                       d_sup_off.p, d_out_off.p, d_syms.p);
+    MALCS_HIP(hipGetLastError());
+    if (2 * count * 8 > (1u << 20)) MALCS_HIP(malcs_sync(st));
+    malcs_batch *b = nullptr;
+    int rc = malcs_batch_create_device(ctx, d_syms.p, total, a_off.data(), a_len.data(), b_off.data(), b_len.data(), count, n_symbols, &b);
+    if (rc) return rc;
+    rc = malcs_dist_launch(b);
+    if (!rc) {
+        hipLaunchKernelGGL(k_relation_verdict, grid, b256, 0, st, h->cells.p, d_ij.p, count, b->d_dist, d_distance.p, h->start.p, d_atoms.p,
+                           d_atom_off.p, h->labels.p);
+        if (hipGetLastError() != hipSuccess) { malcs_set_error("verdict kernel launch failed"); rc = MALCS_ERR_HIP; }
+    }
+    malcs_batch_destroy(b);                    // waits for the stream: the verdicts are in the tiles
+    return rc;
 }
 
 int malcs_relmatrix_tiles(const malcs_relmatrix *h, uint8_t *labels)

@@ -63,6 +63,56 @@ class Prepared:
         self.symmask = np.array(masks, dtype=np.uint64)
 
 
+_DNA = np.full(256, 255, dtype=np.uint8)
+_DNA[[ord(ch) for ch in "ACGT"]] = np.arange(4, dtype=np.uint8)
+
+
+def _dna_codes(text):
+    """str -> codes 0 ... 3, or None when it holds anything but A, C, G, T."""
+    try:
+        codes = _DNA[np.frombuffer(text.encode("latin-1"), dtype=np.uint8)]
+    except UnicodeEncodeError:
+        return None
+    return codes if (len(codes) == 0 or codes.max() < 4) else None
+
+
+def device_inputs(reference, graphs, prep):
+    """What `malcs_relmatrix_decide` needs to settle the undecided pairs on the device, or None when it does not
+    apply (graphs put together by hand, symbols other than A, C, G, T, folded symbol masks): reference and supremal
+    sequences as codes, the graphs' distances, their atom masks (computed by the library from the edge arrays)."""
+    if prep.folded:
+        return None
+    ref = _dna_codes(reference)
+    if ref is None:
+        return None
+    sup = _dna_codes("".join(v.sequence for v in prep.supremal))
+    if sup is None:
+        return None
+    sup_off = np.zeros(len(graphs) + 1, dtype=np.uint64)
+    np.cumsum([len(v.sequence) for v in prep.supremal], out=sup_off[1:])
+    atom_off = np.zeros(len(graphs) + 1, dtype=np.uint64)
+    np.cumsum(prep.end - prep.start + 1, out=atom_off[1:])
+    atoms = np.zeros(int(atom_off[-1]), dtype=np.uint8)
+    by_handle = {}
+    for k, g in enumerate(graphs):
+        result = g.__dict__.get("_result")
+        if result is None:
+            return None
+        by_handle.setdefault(id(result[0]), (result[0], [], []))
+        by_handle[id(result[0])][1].append(k)
+        by_handle[id(result[0])][2].append(result[1])
+    for handle, where, index in by_handle.values():
+        observed = [graphs[k]._observed for k in where]
+        obs = _dna_codes("".join(observed))
+        if obs is None:
+            return None
+        obs_off = np.zeros(len(where) + 1, dtype=np.uint64)
+        np.cumsum([len(x) for x in observed], out=obs_off[1:])
+        where = np.asarray(where)
+        handle.atoms(index, obs, obs_off, np.stack([atom_off[where], atom_off[where + 1]], 1), atoms)
+    return ref, sup, sup_off, prep.distance, atoms, atom_off
+
+
 def compare_matrix(reference, graphs, tile=256, comm=None, rank=0, world=1, gather=None, distance_fn=None, stats=None,
                    tiles_cls=None):
     """uint8 matrix L with L[i, j] = code of compare(reference, graphs[i], graphs[j]).
@@ -103,9 +153,20 @@ def compare_matrix(reference, graphs, tile=256, comm=None, rank=0, world=1, gath
     else:
         tiles = tiles_cls(prep.start, prep.end, prep.key, prep.symmask, tile, rank, world)
     try:
-        # the pairs the pre-filters leave: one batch of edit distances over the union windows
-        pending = tiles.pending()
-        lap("tiles")
+        # the pairs the pre-filters leave: on the device when the library can do all of it there (union windows, one
+        # batch of distances, distance arithmetic, atom masks -- malcs_relmatrix_decide), else one batch of edit
+        # distances over union windows put together here and the verdicts in numpy / Python
+        on_device = device_inputs(reference, graphs, prep) if (tiles_cls is None and hasattr(tiles, "decide")) else None
+        if on_device is not None:
+            lap("device_inputs")
+            n_dp = tiles.decide(*on_device, 4)
+            lap("decide")
+            pending = ()
+            if stats is not None:
+                stats["dp_pairs"] = stats.get("dp_pairs", 0) + n_dp
+        else:
+            pending = tiles.pending()
+            lap("tiles")
         if len(pending):
             li_idx, rj_idx = pending[:, 0], pending[:, 1]
             code = np.full(len(pending), 255, dtype=np.uint8)
@@ -133,6 +194,7 @@ def compare_matrix(reference, graphs, tile=256, comm=None, rank=0, world=1, gath
         if stats is not None:
             stats["dp_pairs"] = stats.get("dp_pairs", 0) + len(pending)
             stats["tiles"] = len(shard(upper_tiles(n, tile), rank, world))
+            stats["decided_on_device"] = on_device is not None
 
         # all-gather of the label tiles
         if comm is not None:

@@ -188,6 +188,14 @@ int malcs_graphs_edges(const malcs_graphs *graphs, uint64_t i, int64_t *edges6);
  * count = number of variants; each is {start, end, obs_from, obs_to}: Variant(start, end, observed[obs_from:obs_to]). */
 int malcs_graphs_canonical_count(malcs_graphs *graphs, uint64_t i, int64_t *count);
 int malcs_graphs_canonical(malcs_graphs *graphs, uint64_t i, int64_t *variants4);
+/* Atom masks of `count` graphs of the handle (pairs index[k]) -- stands in for LCSgraph.uniq_atomics()
+ * (algebra/lcs/lcs_graph.py:207-217) over DNA: for every position p of the supremal's span [start, end] one byte, bit 0
+ * = the atom (p, "") and bit 1 + c = the atom (p, symbol with code c), c = 0 ... 3; two graphs are disjoint
+ * (LCSgraph.is_disjoint, :226-228) iff the masks share no bit at any common position.  obs / obs_off: the observed
+ * sequences of those pairs as codes 0 ... 3, back to back (count + 1 offsets); graph k's end - start + 1 bytes go to
+ * out[out_range[2 k] .. out_range[2 k + 1]). */
+int malcs_graphs_atoms(malcs_graphs *graphs, uint64_t count, const uint64_t *index, const uint8_t *obs, const uint64_t *obs_off,
+                       const uint64_t *out_range, uint8_t *out);
 /* timing split of the last malcs_lcs_graph_batch on this handle, milliseconds:
  * out[0] forward DP kernel, out[1] reach/extract kernel (HIP events), out[2] D2H + host graph build */
 int malcs_graphs_timing(const malcs_graphs *graphs, float *out3);
@@ -221,6 +229,14 @@ int malcs_relmatrix_destroy(malcs_relmatrix *m);
 int malcs_relmatrix_pending_count(const malcs_relmatrix *m, uint64_t *count);
 int malcs_relmatrix_pending(const malcs_relmatrix *m, int64_t *pairs2);
 int malcs_relmatrix_resolve(malcs_relmatrix *m, const uint8_t *codes);
+/* pending + the caller's distance batch + resolve in one call, on the device: for every undecided pair the union
+ * windows (graph_based.py:57-64) are put together from the reference and the supremals' sequences (codes below
+ * n_symbols), their distances computed (:65, kernel family 1), the distance arithmetic applied (:67-74) and what it
+ * leaves open decided from the graphs' atom masks (:76-79; malcs_graphs_atoms).  Arrays per variant as in create;
+ * sup_off / atom_off have n + 1 entries; variant i's atoms cover positions start[i] ... end[i].  *n_dp = pairs that
+ * reached the DP on this rank. */
+int malcs_relmatrix_decide(malcs_relmatrix *m, const uint8_t *ref, uint64_t ref_len, const uint8_t *sup, const uint64_t *sup_off,
+                           const int64_t *distance, const uint8_t *atoms, const uint64_t *atom_off, int n_symbols, uint64_t *n_dp);
 int malcs_relmatrix_tiles(const malcs_relmatrix *m, uint8_t *labels);
 int malcs_relmatrix_assemble(malcs_relmatrix *m, const uint8_t *gathered, uint8_t *full);
 /* The same two steps for a caller whose collective runs on device memory (RCCL): `tiles_device` hands out the
