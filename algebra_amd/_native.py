@@ -153,7 +153,7 @@ _default_ctx = None
 
 
 def default_context():
-    """Context on the device this process owns (LOCAL_RANK, else MALCS_DEVICE, else 0)."""
+    """Context on the device this process owns (MALCS_DEVICE, else LOCAL_RANK, else 0)."""
     global _default_ctx
     if _default_ctx is None:
         device = int(os.environ.get("MALCS_DEVICE", os.environ.get("LOCAL_RANK", "0")))

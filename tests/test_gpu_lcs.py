@@ -690,3 +690,16 @@ def test_pairs_dealt_over_two_contexts(native):
     g1 = LCSgraph.batch(pairs[:60], shifts=range(60))
     g2 = LCSgraph.batch(pairs[:60], shifts=range(60), devices=[0, 0])
     assert [graph_record(g) for g in g1] == [graph_record(g) for g in g2]
+
+
+def test_batch_create_rejects_codes_beyond_n_symbols(native):
+    """The C-ABI does not trust `n_symbols`: a code the promised alphabet does not have is an error, not an alias of
+    another symbol (n_symbols selects the bit planes; code 4 with two planes would read as code 0)."""
+    ctx = native.default_context()
+    syms = np.array([0, 1, 2, 3, 4, 1, 2, 3], np.uint8)
+    args = (np.array([0], np.uint64), np.array([4], np.uint32), np.array([4], np.uint64), np.array([4], np.uint32))
+    with pytest.raises(native.MalcsError, match="n_symbols"):
+        native.Batch(ctx, syms, *args, 4)
+    with pytest.raises(native.MalcsError, match="n_symbols"):
+        native.Batch(ctx, np.array([0, 1, 2, 5, 6, 1, 2, 5], np.uint8), *args, 6)     # three planes hold 0 ... 7, the promise was < 6
+    native.Batch(ctx, syms, *args, 5).close()
