@@ -120,6 +120,7 @@ def extra_configs(ctx, _native, gen):
     wall = time.perf_counter() - t0
     out["c2_lcs_graphs"] = {"pairs": n, "graphs_per_s": round(n / wall, 1), "device_path": "one-wave sweeps (k_sweep_reach + k_sweep_runs)",
                             "backward_sweep_ms": round(float(g.timing[0]), 3), "forward_sweep_ms": round(float(g.timing[1]), 3),
+                            "graphs_built_on_device": int(g.device_built), "device_build_ms": round(float(g.device_build_ms), 3),
                             "host_build_ms": round(float(g.timing[2]), 1)}
     g.close()
     batch.close()
