@@ -161,8 +161,44 @@ bool runs_from_events(event_span ev, int64_t m, int64_t n, std::vector<run> &out
 // The construction itself is malcs_graph_core.hpp (one source for this host path and for the device kernel of
 // malcs_gbuild.hip).  A worker thread keeps one arena and reuses it from pair to pair: no allocation per pair or node.
 struct builder {
-    std::vector<int32_t> mem, runs32;
-    int32_t node_cap = 0, edge_cap = 0, list_cap = 0;
+    std::vector<int32_t> node[9], edge[6], list[2], runs32;             // the arena's arrays, each its own vector
+    malcs_core::arena A;
+    void bind()
+    {
+        int32_t **n[9] = {&A.row, &A.col, &A.length, &A.wlen, &A.incoming, &A.head, &A.tail, &A.id, &A.order};
+        for (int k = 0; k < 9; k++) *n[k] = node[k].data();
+        int32_t **e[6] = {&A.e_child, &A.e_start, &A.e_end, &A.e_from, &A.e_to, &A.e_next};
+        for (int k = 0; k < 6; k++) *e[k] = edge[k].data();
+        A.node_cap = (int32_t)node[0].size(); A.edge_cap = (int32_t)edge[0].size(); A.list_cap = (int32_t)list[0].size();
+    }
+    void start(int32_t nodes, int32_t edges, int32_t lists)
+    {
+        for (auto &v : node) if ((int32_t)v.size() < nodes) v.resize((size_t)nodes);
+        for (auto &v : edge) if ((int32_t)v.size() < edges) v.resize((size_t)edges);
+        for (auto &v : list) if ((int32_t)v.size() < lists) v.resize((size_t)lists);
+        // arrays grown for one graph stay for the next, all of a kind equally long
+        for (auto &v : node) v.resize(node[0].size());
+        for (auto &v : edge) v.resize(edge[0].size());
+        for (auto &v : list) v.resize(list[0].size());
+        bind();
+        A.cur = list[0].data(); A.below = list[1].data();
+        A.n_nodes = A.n_edges = A.n_cur = A.n_below = 0;
+        A.overflow = 0;
+    }
+    // more room for one kind of array, in the middle of a construction: contents stay, the arena is re-pointed
+    bool grow(int which)
+    {
+        auto wider = [](std::vector<int32_t> &v) { if (v.size() > (size_t)1 << 29) return false; v.resize(v.size() * 2); return true; };
+        if (which == malcs_core::GROW_NODES) { for (auto &v : node) if (!wider(v)) return false; }
+        else if (which == malcs_core::GROW_EDGES) { for (auto &v : edge) if (!wider(v)) return false; }
+        else {
+            const bool cur_is_0 = A.cur == list[0].data();
+            for (auto &v : list) if (!wider(v)) return false;
+            A.cur = list[cur_is_0 ? 0 : 1].data(); A.below = list[cur_is_0 ? 1 : 0].data();
+        }
+        bind();
+        return true;
+    }
 };
 
 void build_graph(builder &B, i64_store &store, int64_t m, int64_t n, int64_t shift, const std::vector<run> &runs, int64_t n_levels,
@@ -190,24 +226,21 @@ void build_graph(builder &B, i64_store &store, int64_t m, int64_t n, int64_t shi
         B.runs32[4 * r] = (int32_t)runs[r].row; B.runs32[4 * r + 1] = (int32_t)runs[r].col;
         B.runs32[4 * r + 2] = (int32_t)runs[r].len; B.runs32[4 * r + 3] = (int32_t)runs[r].level;
     }
-    int32_t node_cap = std::max(B.node_cap, 2 * R + 16), edge_cap = std::max(B.edge_cap, 4 * R + 64), list_cap = std::max(B.list_cap, R + 8);
-    malcs_core::arena A;
+    B.start(2 * R + 16, 4 * R + 64, R + 8);
+    malcs_core::arena &A = B.A;
     int32_t source = 0, sink = 0, sup[4] = {0, 0, 0, 0};
-    for (;;) {
-        B.mem.resize((size_t)malcs_core::arena_words(node_cap, edge_cap, list_cap));
-        malcs_core::arena_bind(A, B.mem.data(), node_cap, edge_cap, list_cap);
-        malcs_core::build(A, (int32_t)m, (int32_t)n, shift, B.runs32.data(), R, (int32_t)n_levels, source, sink, sup);
-        if (!A.overflow) break;
-        if (node_cap > (1 << 29) || edge_cap > (1 << 29)) throw std::bad_alloc();
-        node_cap *= 2; edge_cap *= 2; list_cap *= 2;                     // some array was too small: all of them grow
-    }
-    B.node_cap = std::min(node_cap, 1 << 20); B.edge_cap = std::min(edge_cap, 1 << 22); B.list_cap = std::min(list_cap, 1 << 20);
+    malcs_core::build(A, (int32_t)m, (int32_t)n, shift, B.runs32.data(), R, (int32_t)n_levels, source, sink, sup,
+                      [&B](malcs_core::arena &, int which) { return B.grow(which); });
+    if (A.overflow) throw std::bad_alloc();                              // an array beyond 2^30 entries
     int32_t n_edges = 0;
     const int32_t count = malcs_core::number_nodes(A, source, n_edges);
     G.nodes = store.take((size_t)count * 3);
     G.edges = store.take((size_t)n_edges * 6);
     malcs_core::write_graph<int64_t>(A, count, G.nodes.data(), G.edges.data(), shift);
     G.supremal[0] = sup[0] + shift; G.supremal[1] = sup[1] + shift; G.supremal[2] = sup[2]; G.supremal[3] = sup[3];
+    // a thread that has built one graph of a million edges does not keep 100 MB for the small ones that follow
+    if (B.edge[0].size() > ((size_t)1 << 22)) { for (auto &v : B.edge) { v.resize((size_t)1 << 22); v.shrink_to_fit(); } }
+    if (B.node[0].size() > ((size_t)1 << 20)) { for (auto &v : B.node) { v.resize((size_t)1 << 20); v.shrink_to_fit(); } for (auto &v : B.list) { v.resize((size_t)1 << 20); v.shrink_to_fit(); } }
 }
 
 // ---- canonical allele ---------------------------------------------------------------------------

@@ -85,7 +85,7 @@ k_graph_build(uint4 *__restrict__ runs, const uint64_t *__restrict__ run_off, co
         else malcs_core::arena_bind(A, scratch + scratch_off[slot], 2 * (int32_t)R + 16, 8 * (int32_t)R + 64, (int32_t)R + 8);
         const int32_t n_levels = (m + n - dist[pid]) / 2;
         int32_t source = 0, sink = 0, sup[4] = {0, 0, 0, 0};
-        malcs_core::build(A, m, n, shift ? shift[pid] : 0, sorted, (int32_t)R, n_levels, source, sink, sup);
+        malcs_core::build(A, m, n, shift ? shift[pid] : 0, sorted, (int32_t)R, n_levels, source, sink, sup, malcs_core::no_growth());
         int32_t status = A.overflow ? 1 : 0, count = 0, n_edges = 0;
         unsigned long long at = 0;
         if (!status) {

@@ -8,9 +8,10 @@
 // of the sink :451, whose `max_sink` starts at 0 in SHIFTED coordinates -- a sink no edge ever reaches (identical
 // sequences given to LCSgraph() directly) ends up with a length that depends on the shift, so `build` takes it.
 //
-// The working state lives in a caller-provided arena of fixed capacity (LDS or global memory on the device, vectors on
-// the host); running out of room sets `overflow` and keeps going without writing out of bounds, so the caller can
-// retry with a larger arena (host) or hand the pair to the host (device).  Nothing here touches symbols.
+// The working state lives in a caller-provided arena (LDS or global memory on the device, vectors on the host).  When
+// an array is full the caller's `grow(arena, which)` is asked for more room (the host re-allocates that array and
+// re-points the arena; the device has none to give and answers false); without more room `overflow` is set and the
+// construction stops without writing out of bounds, so the pair can be handed to the host.  Nothing here touches symbols.
 #pragma once
 #include <cstdint>
 
@@ -56,17 +57,22 @@ MALCS_HD void arena_bind(arena &A, int32_t *mem, int32_t node_cap, int32_t edge_
     A.overflow = 0;
 }
 
-MALCS_HD int32_t add_node(arena &A, int32_t r, int32_t c, int32_t l)
+enum { GROW_NODES = 0, GROW_EDGES = 1, GROW_LISTS = 2 };
+struct no_growth { MALCS_HD bool operator()(arena &, int) const { return false; } };
+
+template <typename Grow>
+MALCS_HD int32_t add_node(arena &A, int32_t r, int32_t c, int32_t l, Grow &grow)
 {
-    if (A.n_nodes >= A.node_cap) { A.overflow = 1; return A.node_cap - 1; }
+    if (A.n_nodes >= A.node_cap && !(grow(A, GROW_NODES) && A.n_nodes < A.node_cap)) { A.overflow = 1; return A.node_cap - 1; }
     const int32_t v = A.n_nodes++;
     A.row[v] = r; A.col[v] = c; A.length[v] = l; A.wlen[v] = l; A.incoming[v] = 0; A.head[v] = -1; A.tail[v] = -1;
     return v;
 }
 
-MALCS_HD void push_edge(arena &A, int32_t node, int32_t child, int32_t start, int32_t end, int32_t from, int32_t to)
+template <typename Grow>
+MALCS_HD void push_edge(arena &A, int32_t node, int32_t child, int32_t start, int32_t end, int32_t from, int32_t to, Grow &grow)
 {
-    if (A.n_edges >= A.edge_cap) { A.overflow = 1; return; }
+    if (A.n_edges >= A.edge_cap && !(grow(A, GROW_EDGES) && A.n_edges < A.edge_cap)) { A.overflow = 1; return; }
     const int32_t slot = A.n_edges++;
     A.e_child[slot] = child; A.e_start[slot] = start; A.e_end[slot] = end; A.e_from[slot] = from; A.e_to[slot] = to;
     A.e_next[slot] = -1;
@@ -74,35 +80,37 @@ MALCS_HD void push_edge(arena &A, int32_t node, int32_t child, int32_t start, in
     A.tail[node] = slot;
 }
 
-MALCS_HD void copy_edges(arena &A, int32_t dst, int32_t src)
+template <typename Grow>
+MALCS_HD void copy_edges(arena &A, int32_t dst, int32_t src, Grow &grow)
 {
     for (int32_t i = A.head[src]; i >= 0; i = A.e_next[i]) {
         if (A.overflow) return;
-        push_edge(A, dst, A.e_child[i], A.e_start[i], A.e_end[i], A.e_from[i], A.e_to[i]);
+        push_edge(A, dst, A.e_child[i], A.e_start[i], A.e_end[i], A.e_from[i], A.e_to[i], grow);
     }
 }
 
 // runs: 4 int32 per run {row, col, length, level}, sorted by (level, emission order); n_runs >= 1; n_levels = LLCS.
 // On return: A holds the graph, source / sink its end nodes, supremal = {start, end, obs_from, obs_to}.
+template <typename Grow>
 MALCS_HD void build(arena &A, int32_t m, int32_t n, int64_t shift, const int32_t *runs, int32_t n_runs, int32_t n_levels,
-                    int32_t &source, int32_t &sink, int32_t (&supremal)[4])
+                    int32_t &source, int32_t &sink, int32_t (&supremal)[4], Grow grow)
 {
     // Level lists: the runs arrive sorted by level, so level L is a contiguous range of node ids (node id == run index);
     // only two lists are alive at a time (the level being emptied and the one below it) -- the reference's list of
     // ~LLCS lists would cost an allocation per level.
-    for (int32_t r = 0; r < n_runs; r++) add_node(A, runs[4 * r], runs[4 * r + 1], runs[4 * r + 2]);
+    for (int32_t r = 0; r < n_runs; r++) add_node(A, runs[4 * r], runs[4 * r + 1], runs[4 * r + 2], grow);
     if (A.overflow || A.list_cap < 1) { A.overflow = 1; return; }         // node id == run index needs every run in the arena
     int32_t unread = n_runs;                                             // runs [0, unread) are not in a list yet
     const int32_t last = n_runs - 1;                                     // last node of the last level, :379-385
     if (A.row[last] + A.length[last] == m && A.col[last] + A.length[last] == n) {
         unread--;                                                        // popped from its level
-        sink = add_node(A, A.row[last], A.col[last], A.length[last] + 1);
+        sink = add_node(A, A.row[last], A.col[last], A.length[last] + 1, grow);
     } else {
-        sink = add_node(A, m, n, 1);
+        sink = add_node(A, m, n, 1, grow);
     }
-    int32_t *cur = A.cur, *below = A.below;
+    // the lists are used through the arena's pointers: growing them re-points those
     int32_t n_cur = 0, n_below = 0;
-    cur[n_cur++] = sink;
+    A.cur[n_cur++] = sink;
 
     int64_t max_sink = 0;                                                // in shifted coordinates, as the reference's (:387)
     for (int32_t depth = n_levels + 1; depth > 1 && !A.overflow; depth--) {  // depth == len_lcs_nodes, :389
@@ -113,7 +121,7 @@ MALCS_HD void build(arena &A, int32_t m, int32_t n, int64_t shift, const int32_t
         if (idle > 0 && n_cur <= 1) {
             int32_t stride = idle;
             if (n_cur == 1) {
-                const int32_t node = cur[0];
+                const int32_t node = A.cur[0];
                 if (node != sink && A.head[node] < 0) { n_cur = 0; }
                 else { stride = idle < A.wlen[node] - 1 ? idle : A.wlen[node] - 1; A.wlen[node] -= stride; }
             }
@@ -122,30 +130,31 @@ MALCS_HD void build(arena &A, int32_t m, int32_t n, int64_t shift, const int32_t
         int32_t first = unread;
         while (first > 0 && runs[4 * (first - 1) + 3] == depth - 2) first--;
         n_below = 0;
-        if (unread - first > A.list_cap) { A.overflow = 1; break; }
-        for (int32_t i = first; i < unread; i++) below[n_below++] = i;
+        while (unread - first > A.list_cap) if (!grow(A, GROW_LISTS)) { A.overflow = 1; break; }
+        if (A.overflow) break;
+        for (int32_t i = first; i < unread; i++) A.below[n_below++] = i;
         unread = first;
         for (int32_t qi = 0; qi < n_cur && !A.overflow; qi++) {          // pop(0) in order, :390-391
-            const int32_t node = cur[qi];
+            const int32_t node = A.cur[qi];
             if (node != sink && A.head[node] < 0) continue;              // :393-394
             int32_t idx_parent = 0;
             const int32_t nr = A.row[node] + A.wlen[node], nc = A.col[node] + A.wlen[node];
             for (int32_t idx = 0; idx < n_below; idx++) {                // :397
-                const int32_t parent = below[idx];
+                const int32_t parent = A.below[idx];
                 const int32_t pr = A.row[parent] + A.wlen[parent], pc = A.col[parent] + A.wlen[parent];
                 if (pr < nr && pc < nc) {                                // :398 strict dominance of the ends
                     if (node == sink && nr - 1 + shift > max_sink) max_sink = nr - 1 + shift;   // :402-403
                     if (A.incoming[parent] == depth) {                   // :405-412 split the parent
-                        const int32_t split = add_node(A, A.row[parent], A.col[parent], A.length[parent]);
+                        const int32_t split = add_node(A, A.row[parent], A.col[parent], A.length[parent], grow);
                         A.wlen[split] = A.wlen[parent];
-                        copy_edges(A, split, parent);
-                        push_edge(A, split, node, pr, nr - 1, pc, nc - 1);               // :399-400
-                        below[idx] = split;
+                        copy_edges(A, split, parent, grow);
+                        push_edge(A, split, node, pr, nr - 1, pc, nc - 1, grow);               // :399-400
+                        A.below[idx] = split;
                         A.row[parent] += A.wlen[parent];
                         A.col[parent] += A.wlen[parent];
                         A.length[parent] -= A.wlen[parent];
                     } else {
-                        push_edge(A, parent, node, pr, nr - 1, pc, nc - 1);              // :414
+                        push_edge(A, parent, node, pr, nr - 1, pc, nc - 1, grow);              // :414
                     }
                     idx_parent = idx + 1;                                // :416
                 }
@@ -153,28 +162,28 @@ MALCS_HD void build(arena &A, int32_t m, int32_t n, int64_t shift, const int32_t
             if (A.wlen[node] > 1) {                                      // :418-423
                 A.wlen[node] -= 1;
                 if (idx_parent) A.incoming[node] = depth;
-                if (n_below >= A.list_cap) { A.overflow = 1; break; }
-                for (int32_t k = n_below; k > idx_parent; k--) below[k] = below[k - 1];
-                below[idx_parent] = node;
+                if (n_below >= A.list_cap && !(grow(A, GROW_LISTS) && n_below < A.list_cap)) { A.overflow = 1; break; }
+                for (int32_t k = n_below; k > idx_parent; k--) A.below[k] = A.below[k - 1];
+                A.below[idx_parent] = node;
                 n_below++;
             }
         }
-        int32_t *t = cur; cur = below; below = t;                        // :425
+        int32_t *t = A.cur; A.cur = A.below; A.below = t;                // :425
         n_cur = n_below;
     }
 
     if (A.overflow) return;
     int32_t first = 0;                                                   // level 0, :428-432
-    source = n_cur ? cur[0] : sink;
+    source = n_cur ? A.cur[0] : sink;
     if (n_cur && A.row[source] == 0 && A.col[source] == 0) first = 1;
-    else source = add_node(A, 0, 0, 0);
+    else source = add_node(A, 0, 0, 0, grow);
     for (int32_t qi = first; qi < n_cur; qi++) {                         // :434-445
-        const int32_t node = cur[qi];
+        const int32_t node = A.cur[qi];
         if (node != sink && A.head[node] < 0) continue;
         const int32_t nr = A.row[node] + A.wlen[node], nc = A.col[node] + A.wlen[node];
         if (A.row[source] < nr && A.col[source] < nc) {
             if (node == sink && nr - 1 + shift > max_sink) max_sink = nr - 1 + shift;
-            push_edge(A, source, node, A.row[source], nr - 1, A.col[source], nc - 1);
+            push_edge(A, source, node, A.row[source], nr - 1, A.col[source], nc - 1, grow);
         }
     }
     int32_t source_offset = 0;                                           // :447-451

@@ -64,13 +64,42 @@ int main(int argc, char **argv)
                 const int64_t *x = &runs[4 * order[i]];
                 r32[4 * i] = (int32_t)(x[0] - shift); r32[4 * i + 1] = (int32_t)(x[1] - shift); r32[4 * i + 2] = (int32_t)x[2]; r32[4 * i + 3] = (int32_t)x[3];
             }
-            int32_t node_cap = 4, edge_cap = 4, list_cap = 2;            // small on purpose: the overflow paths run too
+            // small arrays on purpose, so that running out of room happens all the time: even cases hand the pair back and
+            // retry with a larger arena (what the device does through the host), odd cases grow in the middle (the host)
+            int32_t node_cap = 4, edge_cap = 4, list_cap = 2;
             for (;;) {
-                std::vector<int32_t> mem((size_t)malcs_core::arena_words(node_cap, edge_cap, list_cap));
+                std::vector<int32_t> node[9], edge[6], list[2];
                 malcs_core::arena A;
-                malcs_core::arena_bind(A, mem.data(), node_cap, edge_cap, list_cap);
+                auto bind = [&]() {
+                    int32_t **np[9] = {&A.row, &A.col, &A.length, &A.wlen, &A.incoming, &A.head, &A.tail, &A.id, &A.order};
+                    for (int k = 0; k < 9; k++) *np[k] = node[k].data();
+                    int32_t **ep[6] = {&A.e_child, &A.e_start, &A.e_end, &A.e_from, &A.e_to, &A.e_next};
+                    for (int k = 0; k < 6; k++) *ep[k] = edge[k].data();
+                    A.node_cap = (int32_t)node[0].size(); A.edge_cap = (int32_t)edge[0].size(); A.list_cap = (int32_t)list[0].size();
+                };
+                for (auto &v : node) v.assign((size_t)node_cap, 0);
+                for (auto &v : edge) v.assign((size_t)edge_cap, 0);
+                for (auto &v : list) v.assign((size_t)list_cap, 0);
+                bind();
+                A.cur = list[0].data(); A.below = list[1].data();
+                A.n_nodes = A.n_edges = A.n_cur = A.n_below = 0; A.overflow = 0;
                 int32_t source = 0, sink = 0, s4[4];
-                malcs_core::build(A, (int32_t)m, (int32_t)n, shift, r32.data(), (int32_t)R, (int32_t)L, source, sink, s4);
+                if (c % 2 == 0) {
+                    malcs_core::build(A, (int32_t)m, (int32_t)n, shift, r32.data(), (int32_t)R, (int32_t)L, source, sink, s4, malcs_core::no_growth());
+                } else {
+                    malcs_core::build(A, (int32_t)m, (int32_t)n, shift, r32.data(), (int32_t)R, (int32_t)L, source, sink, s4,
+                                      [&](malcs_core::arena &, int which) {
+                                          if (which == malcs_core::GROW_NODES) for (auto &v : node) v.resize(v.size() * 2);
+                                          else if (which == malcs_core::GROW_EDGES) for (auto &v : edge) v.resize(v.size() * 2);
+                                          else {
+                                              const bool first = A.cur == list[0].data();
+                                              for (auto &v : list) v.resize(v.size() * 2);
+                                              A.cur = list[first ? 0 : 1].data(); A.below = list[first ? 1 : 0].data();
+                                          }
+                                          bind();
+                                          return true;
+                                      });
+                }
                 if (A.overflow) { node_cap *= 2; edge_cap *= 2; list_cap *= 2; continue; }
                 int32_t ne = 0;
                 const int32_t nn = malcs_core::number_nodes(A, source, ne);
