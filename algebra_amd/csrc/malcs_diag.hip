@@ -154,7 +154,8 @@ k_plan_scatter(const uint32_t *__restrict__ item, uint32_t count, uint32_t hist_
 constexpr uint32_t PIECE_HALF = 1u << 31;     // two-limb mode (T = 48)
 constexpr uint32_t PIECE_JOINED = 1u << 30;   // one of the two pieces of a tile that was cut: the results meet in the join buffer
 constexpr uint32_t PIECE_BACK = 1u << 29;     // ... the one that runs the reversed sequences from the far end
-constexpr uint32_t PIECE_BLOCKS = (1u << 29) - 1u;
+constexpr uint32_t PIECE_CODES = 1u << 28;    // two-limb mode with match masks from LDS: the text rows hold 2-bit symbols, not planes
+constexpr uint32_t PIECE_BLOCKS = (1u << 28) - 1u;
 
 // The rows of every piece.  grid = pieces, 256 threads: lane = slot of the tile, the four waves take the rows of the
 // piece in turn.  A piece that runs backwards gets the rows of the reversed pair: pattern row r' is row m - 1 - r',
@@ -251,12 +252,28 @@ k_diag_layout(const uint32_t *__restrict__ planes, const uint32_t *__restrict__ 
         } else {
             const int it = (int)r - (nlw - 1);
             uint32_t *o = out + (size_t)(nlw - 1) * NP * 64u + (size_t)it * 2u * NP * 64u;
+            uint32_t txt[NP];
 #pragma unroll
             for (int p = 0; p < NP; p++) {
                 const uint32_t v = q ? ((tlo.p[p] >> q) | (thi.p[p] << (32u - q))) : tlo.p[p];
                 o[p * 64u] = limb[p];
-                o[(NP + p) * 64u] = back ? __brev(v) : v;
+                txt[p] = back ? __brev(v) : v;
             }
+            if constexpr (NP == 2) {
+                if (info & PIECE_CODES) {              // symbols of columns 0-15 / 16-31, two bits each (plane 0 = low bit)
+                    auto spread = [](uint32_t x) -> uint32_t {
+                        x &= 0xffffu;
+                        x = (x | (x << 8)) & 0x00ff00ffu; x = (x | (x << 4)) & 0x0f0f0f0fu;
+                        x = (x | (x << 2)) & 0x33333333u; x = (x | (x << 1)) & 0x55555555u;
+                        return x;
+                    };
+                    const uint32_t c0 = spread(txt[0]) | (spread(txt[1]) << 1);
+                    const uint32_t c1 = spread(txt[0] >> 16) | (spread(txt[1] >> 16) << 1);
+                    txt[0] = c0; txt[1] = c1;
+                }
+            }
+#pragma unroll
+            for (int p = 0; p < NP; p++) o[(NP + p) * 64u] = txt[p];
             // the text moves on with the blocks only
             tw += step;
             if (back) { thi = tlo; tlo = stored(to, nt, tw); } else { tlo = thi; thi = stored(to, nt, tw + 1); }
@@ -602,6 +619,51 @@ __device__ __forceinline__ void diag_halves_dna(uint32_t (&V)[3], uint32_t (&P)[
     ones = bank;
 }
 
+// ---- two limbs, match masks from LDS -----------------------------------------------------------------
+// The plane-folding stream above spends 6 of its 10 instructions per column on U = V & Match: two v_bfe_i32 for the text
+// bits and two v_bitop3 per limb.  Here the four match masks of the window (one per symbol, 64 rows) are in LDS and a
+// column costs v_bfe_u32 + v_lshl_or_b32 (symbol -> address), one ds_read2st64_b32 (both limbs, LDS pipe) and one
+// v_and_b32 per limb: 8 VALU instructions per column, two of them 32-bit encodings, 8.7 with everything around them.
+// A lane reads only what it wrote itself (row * 256 + lane * 4), a wave's LDS operations complete in order, so the
+// table needs no barrier; 4 KB per wave.  The stream is generated (tools/gen_diag_lds.py -> malcs_diag_lds.inc): all
+// blocks of a piece are ONE statement with its own loop, the LDS read of a column is issued six columns ahead (across
+// block boundaries), the rows of the next block are loaded by the statement itself (sbase + voff).  The text rows of
+// such a piece hold 2-bit symbols (PIECE_CODES, written by k_diag_layout).
+// On entry: V[0 ... 1] / P[0 ... 1] the limbs the window starts with, nxt the rows of block 0 (they start at
+// rows_u + lane); `ones` collects the one bits of the rows that leave.  The arithmetic is that of diag_halves_dna.
+#include "malcs_diag_lds.inc"
+__device__ __forceinline__ void diag_halves_lds(uint32_t (&V)[3], uint32_t (&P)[3][2], uint32_t &ones, const uint32_t *rows_u,
+                                                unsigned lane, const uint32_t (&nxt)[4], int iters, uint32_t *tab)
+{
+    auto masks = [](uint32_t p0, uint32_t p1, uint32_t (&mk)[4]) {
+        mk[0] = ~(p0 | p1); mk[1] = p0 & ~p1; mk[2] = ~p0 & p1; mk[3] = p0 & p1;
+    };
+    uint32_t m0[4], m1[4];
+    masks(P[0][0], P[0][1], m0);
+    masks(P[1][0], P[1][1], m1);
+#pragma unroll
+    for (int k = 0; k < 4; k++) {
+        tab[(0 + k) * 64 + lane] = m0[k];                                  // aligned ring, slot 0: w[0]
+        tab[(4 + k) * 64 + lane] = m1[k];                                  //               slot 1: w[1]
+        tab[(8 + k) * 64 + lane] = (m0[k] >> 16) | (m1[k] << 16);          // shifted ring, slot 0: (w[1]:w[0]) >> 16
+    }
+    register uint32_t V0 asm("v21") = V[0], V1 asm("v24") = V[1];
+    register uint32_t q0 asm("v44") = m1[0], q1 asm("v45") = m1[1], q2 asm("v46") = m1[2], q3 asm("v47") = m1[3];
+    register uint32_t p0 asm("v28") = nxt[0], p1 asm("v29") = nxt[1], t0 asm("v32") = nxt[2], t1 asm("v36") = nxt[3];
+    register uint32_t base asm("v30") = (uint32_t)reinterpret_cast<uintptr_t>(tab) + lane * 4u;
+    uint32_t voff = lane * 4u, bank = ones;
+    uint32_t cnt = (uint32_t)__builtin_amdgcn_readfirstlane(iters);
+    asm volatile(DIAG_LDS_STREAM
+                 : "+v"(V0), "+v"(V1), "+v"(q0), "+v"(q1), "+v"(q2), "+v"(q3), "+v"(p0), "+v"(p1), "+v"(t0), "+v"(t1),
+                   [bank] "+&v"(bank), [voff] "+&v"(voff), [cnt] "+&s"(cnt), "+v"(base)   // early clobber: voff and base start equal
+                 : [sbase] "s"(rows_u)
+                 : "v22", "v23", "v26", "v27", "v31", "v35", "v33", "v37", "v40", "v41", "v42", "v43", "v48", "v49", "v50", "v51",
+                   "v64", "v65", "v66", "v67", "v68", "v69", "v70", "v71", "v72", "v73", "v74", "v75", "v76", "v77", "v78", "v79",
+                   "s40", "s41", "s44", "s45", "s48", "s49", "scc", "memory");
+    V[0] = V0; V[1] = V1;
+    ones = bank;
+}
+
 // The same for the other classes: loads the compiler does not see, and a wait statement that every
 // destination passes through before its first use (the loads are unconditional: the buffer is padded).
 template <int J>
@@ -653,7 +715,8 @@ k_llcs_diag(const uint32_t *__restrict__ rows, const uint32_t *__restrict__ piec
     if (blockIdx.x == 0 && threadIdx.x < n_classes) retry_count_next[threadIdx.x] = 0u;
     const unsigned lane = threadIdx.x;
     const uint32_t tile = blockIdx.x;
-    const uint32_t *p = rows + (size_t)__builtin_amdgcn_readfirstlane(piece_off[tile]) * 64u + lane;
+    const uint32_t *rows_u = rows + (size_t)__builtin_amdgcn_readfirstlane(piece_off[tile]) * 64u;    // the piece's rows
+    const uint32_t *p = rows_u + lane;
     const uint32_t info = __builtin_amdgcn_readfirstlane(piece_info[tile]);
     const int iters = (int)(info & PIECE_BLOCKS);
     const bool halves = NLW == 3 && NP == 2 && FUSED && (info & PIECE_HALF);     // two limbs, half-limb steps (T = 48)
@@ -696,7 +759,12 @@ k_llcs_diag(const uint32_t *__restrict__ rows, const uint32_t *__restrict__ piec
     if constexpr (NLW == 3 && NP == 2 && FUSED) {
         if (halves) {                                  // every block of every lane is plain (the plan saw to that)
             uint32_t ones = 0;
-            diag_halves_dna(V, P, ones, p, nxt, iters);
+            if (info & PIECE_CODES) {
+                __shared__ __attribute__((aligned(1024))) uint32_t lds_masks[16 * 64];
+                diag_halves_lds(V, P, ones, rows_u + (META_ROWS + (NLW - 1) * NP) * 64, lane, nxt, iters, lds_masks);
+            } else {
+                diag_halves_dna(V, P, ones, p, nxt, iters);
+            }
             if (info & PIECE_JOINED) {
                 // the window now holds rows [32 iters - kmax, + 64) (inside the matrix: the plan leaves two blocks on
                 // either side of a cut); `ones` = one bits of the rows that left
@@ -991,41 +1059,93 @@ static int plan_window(malcs_batch *b, int nlw, const std::vector<uint32_t> &pai
     if (const char *env = getenv("MALCS_DIAG_CUT")) if (*env) cut = n_half > 0 && atoi(env) != 0;
     std::vector<piece> pieces;
     uint32_t n_joins = 0;
+    // MALCS_DIAG_LDS=0: two-limb pieces fold the match masks from the planes (diag_halves_dna) instead of reading them from LDS
+    const bool lds = NP == 2 && !(getenv("MALCS_DIAG_LDS") && atoi(getenv("MALCS_DIAG_LDS")) == 0);
+    const uint32_t half_flags = PIECE_HALF | (lds ? PIECE_CODES : 0u);
     {
-        std::vector<piece> todo;                               // most expensive first (the tiles are sorted by length)
-        todo.reserve(2 * (size_t)n_tiles);
-        for (uint32_t r = 0; r < n_tiles; r++) {
-            const uint32_t t = n_tiles - 1u - r, it = tile_iters[t] & 0x7fffffffu;
-            const bool half = tile_iters[t] >> 31;
-            if (cut && half && it >= 4) {
-                const uint32_t c = std::min(it - 2u, std::max(2u, (it + 1u) / 2u));
-                todo.push_back({t, c, PIECE_HALF | PIECE_JOINED, n_joins});
-                todo.push_back({t, it - c, PIECE_HALF | PIECE_JOINED | PIECE_BACK, n_joins});
-                n_joins++;
-            } else {
-                todo.push_back({t, it, half ? PIECE_HALF : 0u, 0u});
-            }
-        }
         // cost in sixteenths of a three-limb block; a block in two-limb mode costs 0.74
         auto cost = [](const piece &x) -> uint32_t { return x.blocks * ((x.flags & PIECE_HALF) ? 12u : 16u); };
-        std::stable_sort(todo.begin(), todo.end(), [&](const piece &x, const piece &y) { return cost(x) > cost(y); });
-        const uint32_t n = (uint32_t)todo.size();
         struct simd_load { uint64_t load; uint32_t slots, used, idx; };
         auto worse = [](const simd_load &x, const simd_load &y) {   // priority queue: top = least load, then fewest slots
             if (x.load != y.load) return x.load > y.load;
             if (x.slots != y.slots) return x.slots > y.slots;
             return x.idx > y.idx;
         };
-        std::vector<simd_load> heap;
-        for (uint32_t i = 0; i < std::min(S, n); i++) heap.push_back({0, (n - i + S - 1) / S, 0, i});
-        std::make_heap(heap.begin(), heap.end(), worse);
+        // Deals `todo` to the SIMDs [lo, hi) of a launch of n workgroups (SIMD i holds workgroups i, i + S, ...), most
+        // expensive first, each to the least loaded SIMD with a free slot; returns the largest load.
+        auto deal = [&](std::vector<piece> &todo, uint32_t lo, uint32_t hi, uint32_t n, std::vector<piece> &out) -> uint64_t {
+            std::stable_sort(todo.begin(), todo.end(), [&](const piece &x, const piece &y) { return cost(x) > cost(y); });
+            std::vector<simd_load> heap;
+            for (uint32_t i = lo; i < std::min(hi, n); i++) heap.push_back({0, (n - i + S - 1) / S, 0, i});
+            std::make_heap(heap.begin(), heap.end(), worse);
+            uint64_t worst = 0;
+            for (const piece &x : todo) {
+                if (heap.empty()) return ~0ull;                // more pieces than slots: not a plan
+                std::pop_heap(heap.begin(), heap.end(), worse);
+                simd_load &top = heap.back();
+                out[top.idx + top.used * S] = x;
+                top.used++; top.load += cost(x);
+                worst = std::max(worst, top.load);
+                if (top.used == top.slots) heap.pop_back(); else std::push_heap(heap.begin(), heap.end(), worse);
+            }
+            return worst;
+        };
+        auto middle = [](uint32_t it) { return std::min(it - 2u, std::max(2u, (it + 1u) / 2u)); };
+        std::vector<piece> todo;                               // the tiles are sorted by length, shortest first
+        todo.reserve(2 * (size_t)n_tiles);
+        bool uniform = true;                                   // every tile is cut
+        uint64_t total = 0;
+        for (uint32_t t = 0; t < n_tiles; t++) {
+            const uint32_t it = tile_iters[t] & 0x7fffffffu;
+            const bool half = tile_iters[t] >> 31;
+            total += it;
+            if (cut && half && it >= 4) {
+                const uint32_t c = middle(it);
+                todo.push_back({t, c, half_flags | PIECE_JOINED, n_joins});
+                todo.push_back({t, it - c, half_flags | PIECE_JOINED | PIECE_BACK, n_joins});
+                n_joins++;
+            } else {
+                todo.push_back({t, it, half ? half_flags : 0u, 0u});
+                uniform = false;
+            }
+        }
+        const uint32_t n = (uint32_t)todo.size();
         pieces.resize(n);
-        for (uint32_t r = 0; r < n; r++) {
-            std::pop_heap(heap.begin(), heap.end(), worse);
-            simd_load &top = heap.back();
-            pieces[top.idx + top.used * S] = todo[r];
-            top.used++; top.load += cost(todo[r]);
-            if (top.used == top.slots) heap.pop_back(); else std::push_heap(heap.begin(), heap.end(), worse);
+        const uint64_t worst = deal(todo, 0, S, n, pieces);
+        // When n is not a multiple of S, r = n mod S SIMDs hold one piece more than the others, and with every tile cut in
+        // the middle those SIMDs hold (q + 1) / q of the others' work: the launch waits for them (C2: 54 of 1 024 SIMDs
+        // with four pieces of 13 blocks next to three of 15, 28.6 us for 100 000 pairs against 26.5 for 98 304).  A cut
+        // may be anywhere, so the pieces of the smaller group of SIMDs are made as long as that group's share of all
+        // blocks asks for: they come from as many tiles (the shortest when the group holds more pieces per SIMD, else
+        // the longest), whose other parts join the larger group's pieces; either group is dealt on its own.
+        // Kept when its most loaded SIMD is below the plain plan's.  MALCS_DIAG_BALANCE=0: middle cuts only.
+        const uint32_t q = n / S, r = n % S;
+        if (uniform && q >= 1 && r != 0 && !(getenv("MALCS_DIAG_BALANCE") && atoi(getenv("MALCS_DIAG_BALANCE")) == 0)) {
+            const uint64_t na = (uint64_t)r * (q + 1), nb = (uint64_t)(S - r) * q;      // pieces on the fuller / the other SIMDs
+            const bool minor_a = na <= nb;
+            const uint32_t n_ab = (uint32_t)std::min(na, nb);                          // <= n_tiles: na + nb = 2 n_tiles
+            const uint64_t share = (uint64_t)(minor_a ? r : S - r) * total / S;
+            const uint32_t base = (uint32_t)(share / n_ab), extra = (uint32_t)(share % n_ab);
+            std::vector<piece> minor, major;
+            minor.reserve(n_ab); major.reserve(n);
+            for (uint32_t t = 0; t < n_tiles; t++) {
+                const uint32_t it = tile_iters[t] & 0x7fffffffu;
+                const bool ab = minor_a ? t < n_ab : t >= n_tiles - n_ab;
+                if (ab) {
+                    const uint32_t k = minor_a ? t : t - (n_tiles - n_ab);
+                    const uint32_t c = std::min(it - 2u, std::max(2u, base + (k < extra ? 1u : 0u)));
+                    minor.push_back({t, c, half_flags | PIECE_JOINED, t});
+                    major.push_back({t, it - c, half_flags | PIECE_JOINED | PIECE_BACK, t});
+                } else {
+                    const uint32_t c = middle(it);
+                    major.push_back({t, c, half_flags | PIECE_JOINED, t});
+                    major.push_back({t, it - c, half_flags | PIECE_JOINED | PIECE_BACK, t});
+                }
+            }
+            std::vector<piece> alt(n);
+            const uint64_t w0 = deal(minor, minor_a ? 0u : r, minor_a ? r : S, n, alt);
+            const uint64_t w1 = deal(major, minor_a ? r : 0u, minor_a ? S : r, n, alt);
+            if (std::max(w0, w1) < worst) pieces.swap(alt);
         }
     }
     const uint32_t n_pieces = (uint32_t)pieces.size();

@@ -225,6 +225,28 @@ def test_edit_distance_window_class_mixed_tiles(native, nsym):
     assert np.array_equal(got, ref)
 
 
+@pytest.mark.parametrize("lds", ["1", "0"])
+def test_edit_distance_two_limb_pieces(native, lds, monkeypatch):
+    """Two-limb pieces of every length and both parities (whole tiles, front and back parts), with the match masks
+    from LDS (generated stream, malcs_diag_lds.inc) and folded from the planes: same distances as the oracle."""
+    from oracle import oracle as O
+    monkeypatch.setenv("MALCS_DIAG_HALF", "1")
+    monkeypatch.setenv("MALCS_DIAG_LDS", lds)
+    for cut in ("1", "0"):
+        monkeypatch.setenv("MALCS_DIAG_CUT", cut)
+        for length, p, seed in [(70, 0.02, 31), (130, 0.03, 32), (200, 0.02, 33), (330, 0.03, 34), (460, 0.02, 35), (1500, 0.01, 36)]:
+            data = gen.c2_batch(700, seed=seed, length=length, p=p)
+            batch = native.Batch(native.default_context(), *data, n_symbols=4)
+            info = batch.plan_info()
+            got = batch.distances()
+            again = batch.distances()
+            batch.close()
+            ref = O.edit_distance_batch(*data)
+            assert info["two_limb_tiles"] == info["window_tiles"]
+            assert info["window_tiles"] > 0 or length < 330
+            assert np.array_equal(got, ref) and np.array_equal(again, ref), (cut, length)
+
+
 @pytest.mark.parametrize("half", ["0", "1", ""])
 def test_edit_distance_two_limb_mode(native, half, monkeypatch):
     """The two-limb mode of the window class (threshold 48): forced on, forced off and chosen from a sample of the

@@ -1,0 +1,174 @@
+#!/usr/bin/env python3
+"""Writes algebra_amd/csrc/malcs_diag_lds.inc: the instruction stream of the window kernel's two-limb mode with the
+match masks looked up in LDS (one asm statement for all blocks of a piece, k_llcs_diag / diag_halves_lds).
+
+Why generated: the stream is software-pipelined over block boundaries (the LDS read of a column is issued LOOKAHEAD
+columns before its use, into a ring of register pairs) and every s_waitcnt carries the exact number of LDS operations
+issued after the one it waits for; that bookkeeping is easier to get right in a script than in nested C macros.
+
+    python tools/gen_diag_lds.py            # rewrites the .inc; the library's Makefile does not run it
+
+The stream, per block of 32 columns (i = block, e = i % 2; the loop body is an even and an odd block):
+  start   masks of the limb that enters (w[i+2]; four symbols) from its planes; loads of the rows of block i + 1;
+          the masks 16 rows further down (alignbit with the masks of w[i+1]) -> LDS, shifted slot (i + 1) % 2
+  half 0  16 columns on rows (w[i], w[i+1])                      reads: aligned slots i % 2, (i + 1) % 2
+  middle  the window moves down 16 rows; masks of w[i+2] -> LDS, aligned slot i % 2 (w[i] is not read any more)
+  half 1  16 columns on rows ((w[i+1]:w[i]) >> 16, (w[i+2]:w[i+1]) >> 16)   reads: shifted slots i % 2, (i + 1) % 2
+  end     the window moves down 16 rows
+A column: v_bfe_u32 (the column's 2-bit symbol) + v_lshl_or_b32 (LDS address) + ds_read2st64_b32 (both limbs' masks)
+for the column LOOKAHEAD ahead, then per limb v_and_b32, v_add(c)_co_u32, v_bitop3_b32; limb 1 lags one column
+behind limb 0 as in the plane-folding stream, so the carry crosses between steps.
+LDS of a wave: 16 rows of 64 dwords: row (ring * 2 + slot) * 4 + symbol, ring 0 = aligned, 1 = shifted by 16.
+"""
+import os
+
+LOOKAHEAD = 6
+RING = 8                      # register pairs v[64:65] ... v[78:79]
+
+V0, V1 = "v21", "v24"
+U0, S0, U1, S1 = "v22", "v23", "v26", "v27"
+BASE = "v30"                  # lane * 4 (+ the table's LDS offset, a multiple of 1024)
+ADDR = ["v31", "v35"]
+TEXT = [("v32", "v36"), ("v33", "v37")]     # 2-bit symbols of columns 0-15 / 16-31 of an even / odd block
+PL0, PL1 = "v28", "v29"       # planes of the entering limb
+MASKS = [["v40", "v41", "v42", "v43"], ["v44", "v45", "v46", "v47"]]
+SHIFTED = ["v48", "v49", "v50", "v51"]
+CARRY = ["s[40:41]", "s[44:45]"]
+CARRY_TOP = "s[48:49]"
+
+
+def ring(col):
+    k = col % RING
+    return f"v[{64 + 2 * k}:{65 + 2 * k}]", f"v{64 + 2 * k}", f"v{65 + 2 * k}"
+
+
+class Stream:
+    def __init__(self):
+        self.lines = []
+        self.ds_issued = 0
+        self.read_at = {}         # column (absolute, block-relative numbering below) -> index of its ds_read
+        self.addr_turn = 0
+
+    def emit(self, s):
+        self.lines.append(s)
+
+    def ds(self, s):
+        self.emit(s)
+        self.ds_issued += 1
+
+    def wait_read(self, key):
+        later = self.ds_issued - self.read_at.pop(key) - 1
+        assert 0 <= later <= 15, later
+        self.emit(f"s_waitcnt lgkmcnt({later})")
+
+
+def read_column(st, e, G, key):
+    """Issue the LDS read of column G (0 ... 31 this block of parity e, 32 ... the next block)."""
+    if G < 16:
+        text, bit, lo, hi = TEXT[e][0], 2 * G, 4 * e, 4 * (1 - e)
+    elif G < 32:
+        text, bit, lo, hi = TEXT[e][1], 2 * (G - 16), 8 + 4 * e, 8 + 4 * (1 - e)
+    else:
+        text, bit, lo, hi = TEXT[1 - e][0], 2 * (G - 32), 4 * (1 - e), 4 * e
+    a = ADDR[st.addr_turn]
+    st.addr_turn ^= 1
+    pair, _, _ = ring(G)
+    st.emit(f"v_bfe_u32 {a}, {text}, {bit}, 2")
+    st.emit(f"v_lshl_or_b32 {a}, {a}, 8, {BASE}")
+    st.read_at[key] = st.ds_issued
+    st.ds(f"ds_read2st64_b32 {pair}, {a} offset0:{lo} offset1:{hi}")
+
+
+def window_down(st):
+    st.emit(f"v_and_b32 {U0}, 0xffff, {V0}")
+    st.emit(f"v_bcnt_u32_b32 %[bank], {U0}, %[bank]")
+    st.emit(f"v_alignbit_b32 {V0}, {V1}, {V0}, 16")
+    st.emit(f"v_alignbit_b32 {V1}, -1, {V1}, 16")
+
+
+def block(st, e, row_offset):
+    new, prev = MASKS[e], MASKS[1 - e]
+    # masks of the entering limb: symbol = plane 0 bit | plane 1 bit << 1
+    st.emit(f"v_and_b32 {new[3]}, {PL0}, {PL1}")
+    st.emit(f"v_bitop3_b32 {new[0]}, {PL0}, {PL1}, {PL1} bitop3:0x03")
+    st.emit(f"v_xor_b32 {new[1]}, {PL0}, {new[3]}")
+    st.emit(f"v_xor_b32 {new[2]}, {PL1}, {new[3]}")
+    nt = TEXT[1 - e]
+    st.emit(f"global_load_dword {PL0}, %[voff], %[sbase] offset:{row_offset}")
+    st.emit(f"global_load_dword {PL1}, %[voff], %[sbase] offset:{row_offset + 256}")
+    st.emit(f"global_load_dword {nt[0]}, %[voff], %[sbase] offset:{row_offset + 512}")
+    st.emit(f"global_load_dword {nt[1]}, %[voff], %[sbase] offset:{row_offset + 768}")
+    for k in range(4):
+        st.emit(f"v_alignbit_b32 {SHIFTED[k]}, {new[k]}, {prev[k]}, 16")
+    slot = 8 + 4 * (1 - e)
+    st.ds(f"ds_write2st64_b32 {BASE}, {SHIFTED[0]}, {SHIFTED[1]} offset0:{slot} offset1:{slot + 1}")
+    st.ds(f"ds_write2st64_b32 {BASE}, {SHIFTED[2]}, {SHIFTED[3]} offset0:{slot + 2} offset1:{slot + 3}")
+    for h in range(2):
+        for s in range(17):
+            g = 16 * h + s
+            if s < 16:
+                if h == 1 and s == 16 - LOOKAHEAD:
+                    st.emit("s_waitcnt vmcnt(0)")           # the next block's text is read from here on
+                read_column(st, e, g + LOOKAHEAD, ("n", g + LOOKAHEAD - 32) if g + LOOKAHEAD >= 32 else ("c", g + LOOKAHEAD))
+            if s >= 1:
+                st.emit(f"v_and_b32 {U1}, {V1}, {ring(g - 1)[2]}")
+            if s < 16:
+                st.wait_read(("c", g))
+                st.emit(f"v_and_b32 {U0}, {V0}, {ring(g)[1]}")
+            if s >= 1:
+                st.emit(f"v_addc_co_u32_e64 {S1}, {CARRY_TOP}, {V1}, {U1}, {CARRY[(s - 1) % 2]}")
+            if s < 16:
+                st.emit(f"v_add_co_u32_e64 {S0}, {CARRY[s % 2]}, {V0}, {U0}")
+            if s >= 1:
+                st.emit(f"v_bitop3_b32 {V1}, {U1}, {S1}, {V1} bitop3:0xde")
+            if s < 16:
+                st.emit(f"v_bitop3_b32 {V0}, {U0}, {S0}, {V0} bitop3:0xde")
+        window_down(st)
+        if h == 0:
+            slot = 4 * e
+            st.ds(f"ds_write2st64_b32 {BASE}, {new[0]}, {new[1]} offset0:{slot} offset1:{slot + 1}")
+            st.ds(f"ds_write2st64_b32 {BASE}, {new[2]}, {new[3]} offset0:{slot + 2} offset1:{slot + 3}")
+    # what is in flight now belongs to the next block
+    assert all(k[0] == "n" for k in st.read_at), st.read_at
+    st.read_at = {("c", k[1]): v for k, v in st.read_at.items()}
+
+
+def generate():
+    st = Stream()
+    for g in range(LOOKAHEAD):
+        read_column(st, 0, g, ("c", g))
+    entry = {k: st.ds_issued - v for k, v in st.read_at.items()}
+    st.emit("Ldiag_lds_loop%=:")
+    block(st, 0, 1024)
+    st.emit("s_sub_u32 %[cnt], %[cnt], 1")
+    st.emit("s_cmp_eq_u32 %[cnt], 0")
+    st.emit("s_cbranch_scc1 Ldiag_lds_done%=")
+    block(st, 1, 2048)
+    st.emit("v_add_u32 %[voff], 0x800, %[voff]")
+    st.emit("s_sub_u32 %[cnt], %[cnt], 1")
+    st.emit("s_cmp_eq_u32 %[cnt], 0")
+    st.emit("s_cbranch_scc0 Ldiag_lds_loop%=")
+    # the reads in flight at the end of either block were issued back to back, like the ones of the preamble
+    assert {k: st.ds_issued - v for k, v in st.read_at.items()} == entry
+    st.emit("Ldiag_lds_done%=:")
+    st.emit("s_waitcnt vmcnt(0) lgkmcnt(0)")
+    return st.lines
+
+
+def main():
+    lines = generate()
+    out = os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "algebra_amd", "csrc", "malcs_diag_lds.inc")
+    with open(out, "w") as f:
+        f.write("// Generated by tools/gen_diag_lds.py -- do not edit.  The two-limb window stream with match masks from LDS\n")
+        f.write(f"// (lookahead {LOOKAHEAD} columns, ring of {RING} register pairs); registers and operands: see diag_halves_lds.\n")
+        f.write("#define DIAG_LDS_STREAM \\\n")
+        for i, line in enumerate(lines):
+            end = "\\n\\t" if i + 1 < len(lines) else ""
+            cont = " \\" if i + 1 < len(lines) else ""
+            f.write(f'    "{line}{end}"{cont}\n')
+    n_valu = sum(1 for l in lines if l.startswith("v_"))
+    print(f"{len(lines)} lines, {n_valu} VALU instructions for two blocks + preamble -> {n_valu / 64:.2f} per column")
+
+
+if __name__ == "__main__":
+    main()
