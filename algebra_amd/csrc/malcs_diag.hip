@@ -708,7 +708,7 @@ k_llcs_diag(const uint32_t *__restrict__ rows, const uint32_t *__restrict__ piec
             uint32_t *__restrict__ retry_list, const uint32_t *__restrict__ retry_first,
             const uint32_t *__restrict__ retry_cap, uint32_t *__restrict__ retry_count,
             uint32_t *__restrict__ retry_count_next, uint32_t n_classes,
-            uint32_t *__restrict__ join_buf, uint32_t *__restrict__ join_flag)
+            uint32_t *__restrict__ join_buf)
 {
     constexpr int T = 32 * NLW - 32;
     // the counters of the NEXT launch start at zero: nothing in flight reads or writes that set now
@@ -755,7 +755,7 @@ k_llcs_diag(const uint32_t *__restrict__ rows, const uint32_t *__restrict__ piec
     }
 
     int32_t d = 0;
-    bool have_d = false;
+    bool have_d = false, skip = false;                 // skip: the other part of the tile reports this lane's pair
     if constexpr (NLW == 3 && NP == 2 && FUSED) {
         if (halves) {                                  // every block of every lane is plain (the plan saw to that)
             uint32_t ones = 0;
@@ -767,46 +767,50 @@ k_llcs_diag(const uint32_t *__restrict__ rows, const uint32_t *__restrict__ piec
             }
             if (info & PIECE_JOINED) {
                 // the window now holds rows [32 iters - kmax, + 64) (inside the matrix: the plan leaves two blocks on
-                // either side of a cut); `ones` = one bits of the rows that left
+                // either side of a cut); `ones` = one bits of the rows that left.  The join needs 48 of the 64 rows and
+                // the count, which fit one 64-bit word: every lane SWAPS its word into the tile's slot (agent scope: one
+                // trip to memory, coherent across the XCDs' L2s by itself).  Zero comes back to the part that finishes
+                // first, which is done; the other part gets the first one's word, joins, and clears the slot for the
+                // next launch.  (Round 2 began with three stores, a wait, an atomic add on a flag per tile and three
+                // loads: three round trips in a row at the end of every launch; a __threadfence() in place of the wait
+                // writes back and invalidates the whole L2 per wave, 35 -> 103 us.)
                 const uint32_t jt = __builtin_amdgcn_readfirstlane(piece_join[tile]);
-                const uint32_t back = (info & PIECE_BACK) ? 1u : 0u;
-                uint32_t *mine = join_buf + ((size_t)jt * 2u + back) * 192u + lane;
-                const uint32_t *theirs = join_buf + ((size_t)jt * 2u + (back ^ 1u)) * 192u + lane;
-                __hip_atomic_store(mine, V[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                __hip_atomic_store(mine + 64, V[1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                __hip_atomic_store(mine + 128, ones, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                // The three stores and the loads below are agent-scope atomics (write-through / coherent across the
-                // XCDs' L2s by themselves), so no cache write-back or invalidation is needed, only order: the stores
-                // have completed before lane 0 announces them.  (A __threadfence() here writes back and invalidates
-                // the whole L2 per wave: 35 -> 103 us for the C2 launch.)
-                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-                uint32_t first = 0;
-                if (lane == 0) first = __hip_atomic_fetch_add(&join_flag[jt], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                first = __builtin_amdgcn_readfirstlane(first);
-                if (first == 0u) return;               // the other part is still at work: it will join
-                asm volatile("" ::: "memory");
-                if (lane == 0) __hip_atomic_store(&join_flag[jt], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // for the next launch
-                const uint32_t o0 = __hip_atomic_load(theirs, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                const uint32_t o1 = __hip_atomic_load(theirs + 64, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                const uint32_t oo = __hip_atomic_load(theirs + 128, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                const bool back = info & PIECE_BACK;
+                skip = true;
                 if (pid != 0xffffffffu) {
-                    const uint64_t mv = ((uint64_t)V[1] << 32) | V[0], ov = ((uint64_t)o1 << 32) | o0;
-                    const uint64_t Vf = back ? ov : mv, Vb = back ? mv : ov;
-                    const int S = 2 * kmax - (int)(n - m);                       // 47 or 48
-                    const uint64_t A = ~Vf, B = ~Vb & ((1ull << S) - 1ull);
-                    const uint64_t Br = __brevll(B) >> (64 - S);                 // bit x: row S - 1 - x of the back window
-                    const uint32_t a0 = (uint32_t)A, a1 = (uint32_t)(A >> 32), b0 = (uint32_t)Br, b1 = (uint32_t)(Br >> 32);
-                    int cur = __popcll(B), best = cur;                           // x = 0: nothing of the front window, S rows of the back one
+                    unsigned long long *slot = reinterpret_cast<unsigned long long *>(join_buf) + (size_t)jt * 64u + lane;
+                    const uint64_t mv = (((uint64_t)V[1] << 32) | V[0]) & 0xffffffffffffull;
+                    const uint64_t theirs = __hip_atomic_exchange(slot, mv | ((uint64_t)(ones + 1u) << 48), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    if (theirs != 0ull) {
+                        __hip_atomic_store(slot, 0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        const uint64_t ov = theirs & 0xffffffffffffull;
+                        const uint32_t oo = (uint32_t)(theirs >> 48) - 1u;
+                        const uint64_t Vf = back ? ov : mv, Vb = back ? mv : ov;
+                        const int S = 2 * kmax - (int)(n - m);                       // 47 or 48
+                        const uint64_t A = ~Vf, B = ~Vb & ((1ull << S) - 1ull);
+                        const uint64_t Br = __brevll(B) >> (64 - S);                 // bit x: row S - 1 - x of the back window
+                        const uint32_t a0 = (uint32_t)A, a1 = (uint32_t)(A >> 32), b0 = (uint32_t)Br, b1 = (uint32_t)(Br >> 32);
+                        // x = 0: nothing of the front window, S rows of the back one; step x moves row x from the back
+                        // window's side to the front one's.  Three stretches of the walk side by side (total and largest
+                        // prefix of each): the wave is alone on its SIMD by now, and one chain of 48 steps would wait
+                        // for itself.
+                        int t0 = 0, t1 = 0, t2 = 0, m0 = 0, m1 = 0, m2 = 0;
 #pragma unroll
-                    for (int x = 0; x < 32; x++) { cur += (int)((a0 >> x) & 1u) - (int)((b0 >> x) & 1u); best = max(best, cur); }
-#pragma unroll
-                    for (int x = 0; x < MALCS_DIAG_HALF_T - 33; x++) { cur += (int)((a1 >> x) & 1u) - (int)((b1 >> x) & 1u); best = max(best, cur); }
-                    cur += (int)((a1 >> (MALCS_DIAG_HALF_T - 33)) & 1u) - (int)((b1 >> (MALCS_DIAG_HALF_T - 33)) & 1u);   // x = 47: only when S = 48
-                    if (S == MALCS_DIAG_HALF_T) best = max(best, cur);
-                    // zero bits of the rows that left either window (all inside the matrix but the kmax rows above it)
-                    const uint32_t zeros = n - ones - oo - 2u * (uint32_t)kmax + (uint32_t)best;
-                    d = (int32_t)(m + n - 2u * zeros);
-                    have_d = true;
+                        for (int x = 0; x < 16; x++) {
+                            t0 += (int)((a0 >> x) & 1u) - (int)((b0 >> x) & 1u); m0 = max(m0, t0);
+                            t1 += (int)((a0 >> (16 + x)) & 1u) - (int)((b0 >> (16 + x)) & 1u); m1 = max(m1, t1);
+                            if (x < MALCS_DIAG_HALF_T - 33) { t2 += (int)((a1 >> x) & 1u) - (int)((b1 >> x) & 1u); m2 = max(m2, t2); }
+                        }
+                        int best = max(max(m0, t0 + m1), t0 + t1 + m2);
+                        if (S == MALCS_DIAG_HALF_T)                                  // x = 47
+                            best = max(best, t0 + t1 + t2 + (int)((a1 >> (MALCS_DIAG_HALF_T - 33)) & 1u) - (int)((b1 >> (MALCS_DIAG_HALF_T - 33)) & 1u));
+                        best += __popcll(B);
+                        // zero bits of the rows that left either window (all inside the matrix but the kmax rows above it)
+                        const uint32_t zeros = n - ones - oo - 2u * (uint32_t)kmax + (uint32_t)best;
+                        d = (int32_t)(m + n - 2u * zeros);
+                        have_d = true;
+                        skip = false;
+                    }
                 }
             } else {
                 banked = 32u * (uint32_t)iters - ones;
@@ -814,7 +818,7 @@ k_llcs_diag(const uint32_t *__restrict__ rows, const uint32_t *__restrict__ piec
             }
         }
     }
-    if (!have_d) {
+    if (!have_d && !(halves && (info & PIECE_JOINED))) {
         for (int it = halves ? iters : 0; it < iters;) {
             if constexpr (NLW == 3 && NP == 2 && FUSED) {
                 auto plain3 = [&](int i) { return i + 3 <= iters && __builtin_amdgcn_ballot_w64(i + 3 > plain_hi) == 0; };
@@ -862,7 +866,7 @@ k_llcs_diag(const uint32_t *__restrict__ rows, const uint32_t *__restrict__ piec
         d = (int32_t)(m + n - 2u * zeros);
     }
 
-    if (pid != 0xffffffffu) {
+    if (pid != 0xffffffffu && !skip) {
         if (d <= (halves ? MALCS_DIAG_HALF_T : T)) {
             dist[pid] = d;
         } else {
@@ -874,7 +878,7 @@ k_llcs_diag(const uint32_t *__restrict__ rows, const uint32_t *__restrict__ piec
 }
 
 typedef void (*diag_kernel_t)(const uint32_t *, const uint32_t *, const uint32_t *, const uint32_t *, int32_t *, uint32_t *,
-                              const uint32_t *, const uint32_t *, uint32_t *, uint32_t *, uint32_t, uint32_t *, uint32_t *);
+                              const uint32_t *, const uint32_t *, uint32_t *, uint32_t *, uint32_t, uint32_t *);
 template <int NP>
 diag_kernel_t pick_diag(int nlw)
 {
@@ -1099,7 +1103,7 @@ static int plan_window(malcs_batch *b, int nlw, const std::vector<uint32_t> &pai
             const uint32_t it = tile_iters[t] & 0x7fffffffu;
             const bool half = tile_iters[t] >> 31;
             total += it;
-            if (cut && half && it >= 4) {
+            if (cut && half && it >= 4 && it <= 2040) {    // the join word holds the ones of at most 2 046 blocks
                 const uint32_t c = middle(it);
                 todo.push_back({t, c, half_flags | PIECE_JOINED, n_joins});
                 todo.push_back({t, it - c, half_flags | PIECE_JOINED | PIECE_BACK, n_joins});
@@ -1118,9 +1122,12 @@ static int plan_window(malcs_batch *b, int nlw, const std::vector<uint32_t> &pai
         // may be anywhere, so the pieces of the smaller group of SIMDs are made as long as that group's share of all
         // blocks asks for: they come from as many tiles (the shortest when the group holds more pieces per SIMD, else
         // the longest), whose other parts join the larger group's pieces; either group is dealt on its own.
-        // Kept when its most loaded SIMD is below the plain plan's.  MALCS_DIAG_BALANCE=0: middle cuts only.
+        // Kept when its most loaded SIMD is below the plain plan's, and only from two pieces per SIMD on: below that a
+        // SIMD's time is not its blocks (one wave alone issues at two thirds of the rate of two), and two short pieces
+        // side by side beat a long one alone (50 000 pairs: 18.3 us with middle cuts, 21.3 balanced).
+        // MALCS_DIAG_BALANCE=0: middle cuts only.
         const uint32_t q = n / S, r = n % S;
-        if (uniform && q >= 1 && r != 0 && !(getenv("MALCS_DIAG_BALANCE") && atoi(getenv("MALCS_DIAG_BALANCE")) == 0)) {
+        if (uniform && q >= 2 && r != 0 && !(getenv("MALCS_DIAG_BALANCE") && atoi(getenv("MALCS_DIAG_BALANCE")) == 0)) {
             const uint64_t na = (uint64_t)r * (q + 1), nb = (uint64_t)(S - r) * q;      // pieces on the fuller / the other SIMDs
             const bool minor_a = na <= nb;
             const uint32_t n_ab = (uint32_t)std::min(na, nb);                          // <= n_tiles: na + nb = 2 n_tiles
@@ -1176,7 +1183,7 @@ static int plan_window(malcs_batch *b, int nlw, const std::vector<uint32_t> &pai
     const size_t at_tab = carve(keep, piece_tab.size());
     const size_t at_list = carve(keep, std::max<uint32_t>(acc, 1)), at_first = carve(keep, ncls), at_cap = carve(keep, ncls);
     const size_t at_count = carve(keep, 2 * ncls);                         // two sets, used by alternate launches
-    const size_t at_jbuf = carve(keep, (size_t)n_joins * 384u), at_jflag = carve(keep, std::max(n_joins, 1u));
+    const size_t at_jbuf = carve(keep, (size_t)std::max(n_joins, 1u) * 128u);   // one 64-bit word per lane of a cut tile
     const size_t at_titers = carve(keep, n_tiles);
     MALCS_HIP(malcs_pool_alloc(ctx, (void **)&d.d_rows, keep * sizeof(uint32_t)));
     (void)at_rows;                                                         // the rows come first: d_rows is the allocation
@@ -1184,7 +1191,7 @@ static int plan_window(malcs_batch *b, int nlw, const std::vector<uint32_t> &pai
     d.d_piece_off = tab; d.d_piece_info = tab + n_pieces + 1; d.d_piece_join = tab + 3 * (size_t)n_pieces + 1;
     uint32_t *const d_piece_tile = tab + 2 * (size_t)n_pieces + 1, *const d_tile_iters = d.d_rows + at_titers;
     d.d_retry_list = d.d_rows + at_list; d.d_retry_first = d.d_rows + at_first; d.d_retry_cap = d.d_rows + at_cap;
-    d.d_retry_count = d.d_rows + at_count; d.d_join_buf = d.d_rows + at_jbuf; d.d_join_flag = d.d_rows + at_jflag;
+    d.d_retry_count = d.d_rows + at_count; d.d_join_buf = d.d_rows + at_jbuf;
     MALCS_HIP(malcs_h2d(st, tab, piece_tab.data(), piece_tab.size() * sizeof(uint32_t)));
     MALCS_HIP(malcs_h2d(st, d_tile_iters, tile_iters.data(), n_tiles * sizeof(uint32_t)));
     MALCS_HIP(malcs_h2d(st, d_hist, start.data(), start.size() * sizeof(uint32_t)));          // the histogram becomes the cursors
@@ -1193,7 +1200,7 @@ static int plan_window(malcs_batch *b, int nlw, const std::vector<uint32_t> &pai
         MALCS_HIP(malcs_h2d(st, d.d_retry_cap, cap.data(), classes.size() * sizeof(uint32_t)));
     }
     MALCS_HIP(hipMemsetAsync(d.d_retry_count, 0, 2 * ncls * sizeof(uint32_t), st));
-    MALCS_HIP(hipMemsetAsync(d.d_join_flag, 0, std::max(n_joins, 1u) * sizeof(uint32_t), st));
+    MALCS_HIP(hipMemsetAsync(d.d_join_buf, 0, (size_t)std::max(n_joins, 1u) * 128u * sizeof(uint32_t), st));
     MALCS_HIP(hipMemsetAsync(d_slot, 0xff, (size_t)n_tiles * 64u * sizeof(uint32_t), st));
     hipLaunchKernelGGL(k_plan_scatter, dim3((count + 1023u) / 1024u), dim3(1024), 2 * hist_lds, st, d_item, count, HB, d_hist, d_slot);
     switch (NP) {
@@ -1237,7 +1244,7 @@ int malcs_diag_launch(malcs_batch *b, bool advance)
     if (advance) d.parity ^= 1u;
     uint32_t *cur = d.d_retry_count + d.parity * ncls, *next = d.d_retry_count + (d.parity ^ 1u) * ncls;
     hipLaunchKernelGGL(fn, dim3(d.n_pieces), dim3(64), 0, st, d.d_rows, d.d_piece_off, d.d_piece_info, d.d_piece_join, b->d_dist,
-                       d.d_retry_list, d.d_retry_first, d.d_retry_cap, cur, next, advance ? ncls : 0u, d.d_join_buf, d.d_join_flag);
+                       d.d_retry_list, d.d_retry_first, d.d_retry_cap, cur, next, advance ? ncls : 0u, d.d_join_buf);
     MALCS_HIP(hipGetLastError());
     return MALCS_OK;
 }

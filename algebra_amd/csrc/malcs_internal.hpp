@@ -162,7 +162,7 @@ struct diag_plan {
     uint32_t *d_piece_off = nullptr;     // first row of each piece
     uint32_t *d_piece_info = nullptr;    // column blocks of each piece | mode flags
     uint32_t *d_piece_join = nullptr;    // for the pieces of a cut tile: which slot of the join buffer they meet in
-    uint32_t *d_join_buf = nullptr, *d_join_flag = nullptr;
+    uint32_t *d_join_buf = nullptr;
     uint32_t *d_retry_list = nullptr, *d_retry_first = nullptr, *d_retry_cap = nullptr, *d_retry_count = nullptr;
     std::vector<diag_retry> retry;
     uint32_t parity = 0;                 // which of the two sets of retry counters the last launch used

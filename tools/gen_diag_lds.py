@@ -37,6 +37,22 @@ CARRY = ["s[40:41]", "s[44:45]"]
 CARRY_TOP = "s[48:49]"
 
 
+ALIGN4 = int(os.environ.get("GEN_ALIGN4", "0"))       # keep 64-bit encodings at addresses = 4 (mod 8), see DESIGN section 4
+ALIGNED_KINDS = ("v_", "ds_")
+
+
+def insn_size(s):
+    """Bytes of an instruction of this stream (gfx950 encodings)."""
+    op = s.split()[0]
+    if op.endswith(":"):
+        return 0
+    if op.startswith("s_"):
+        return 4
+    if op in ("v_and_b32", "v_xor_b32", "v_add_u32", "v_bcnt_u32_b32"):
+        return 8 if "0x" in s else 4          # VOP2, + 4 with a literal
+    return 8                                  # VOP3, DS, GLOBAL
+
+
 def ring(col):
     k = col % RING
     return f"v[{64 + 2 * k}:{65 + 2 * k}]", f"v{64 + 2 * k}", f"v{65 + 2 * k}"
@@ -48,9 +64,17 @@ class Stream:
         self.ds_issued = 0
         self.read_at = {}         # column (absolute, block-relative numbering below) -> index of its ds_read
         self.addr_turn = 0
+        self.pos = 0              # bytes from the last .p2align 3
+        self.nops = 0
 
     def emit(self, s):
+        size = insn_size(s)
+        if ALIGN4 and size == 8 and self.pos % 8 == 0 and s.startswith(ALIGNED_KINDS):
+            self.lines.append("s_nop 0")
+            self.pos += 4
+            self.nops += 1
         self.lines.append(s)
+        self.pos += size
 
     def ds(self, s):
         self.emit(s)
@@ -106,12 +130,12 @@ def block(st, e, row_offset):
     for h in range(2):
         for s in range(17):
             g = 16 * h + s
+            if s >= 1:
+                st.emit(f"v_and_b32 {U1}, {V1}, {ring(g - 1)[2]}")
             if s < 16:
                 if h == 1 and s == 16 - LOOKAHEAD:
                     st.emit("s_waitcnt vmcnt(0)")           # the next block's text is read from here on
                 read_column(st, e, g + LOOKAHEAD, ("n", g + LOOKAHEAD - 32) if g + LOOKAHEAD >= 32 else ("c", g + LOOKAHEAD))
-            if s >= 1:
-                st.emit(f"v_and_b32 {U1}, {V1}, {ring(g - 1)[2]}")
             if s < 16:
                 st.wait_read(("c", g))
                 st.emit(f"v_and_b32 {U0}, {V0}, {ring(g)[1]}")
@@ -138,6 +162,8 @@ def generate():
     for g in range(LOOKAHEAD):
         read_column(st, 0, g, ("c", g))
     entry = {k: st.ds_issued - v for k, v in st.read_at.items()}
+    st.lines.append(".p2align 3")
+    st.pos = 0
     st.emit("Ldiag_lds_loop%=:")
     block(st, 0, 1024)
     st.emit("s_sub_u32 %[cnt], %[cnt], 1")
@@ -167,7 +193,8 @@ def main():
             cont = " \\" if i + 1 < len(lines) else ""
             f.write(f'    "{line}{end}"{cont}\n')
     n_valu = sum(1 for l in lines if l.startswith("v_"))
-    print(f"{len(lines)} lines, {n_valu} VALU instructions for two blocks + preamble -> {n_valu / 64:.2f} per column")
+    print(f"{len(lines)} lines, {n_valu} VALU instructions for two blocks + preamble -> {n_valu / 64:.2f} per column, "
+          f"{sum(1 for l in lines if l == 's_nop 0')} s_nop")
 
 
 if __name__ == "__main__":
