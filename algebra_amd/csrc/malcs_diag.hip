@@ -36,6 +36,7 @@
 #include <atomic>
 #include <cstdlib>
 #include <cstring>
+#include <functional>
 #include <system_error>
 #include <thread>
 #include <utility>
@@ -1069,28 +1070,27 @@ static int plan_window(malcs_batch *b, int nlw, const std::vector<uint32_t> &pai
     {
         // cost in sixteenths of a three-limb block; a block in two-limb mode costs 0.74
         auto cost = [](const piece &x) -> uint32_t { return x.blocks * ((x.flags & PIECE_HALF) ? 12u : 16u); };
-        struct simd_load { uint64_t load; uint32_t slots, used, idx; };
-        auto worse = [](const simd_load &x, const simd_load &y) {   // priority queue: top = least load, then fewest slots
-            if (x.load != y.load) return x.load > y.load;
-            if (x.slots != y.slots) return x.slots > y.slots;
-            return x.idx > y.idx;
-        };
         // Deals `todo` to the SIMDs [lo, hi) of a launch of n workgroups (SIMD i holds workgroups i, i + S, ...), most
-        // expensive first, each to the least loaded SIMD with a free slot; returns the largest load.
+        // expensive first, each to the least loaded SIMD with a free slot (ties: fewest slots, then lowest number);
+        // returns the largest load.  Heap of packed keys: load << 32 | slots << 16 | SIMD.
+        std::vector<uint64_t> heap;
+        std::vector<uint32_t> used;
         auto deal = [&](std::vector<piece> &todo, uint32_t lo, uint32_t hi, uint32_t n, std::vector<piece> &out) -> uint64_t {
             std::stable_sort(todo.begin(), todo.end(), [&](const piece &x, const piece &y) { return cost(x) > cost(y); });
-            std::vector<simd_load> heap;
-            for (uint32_t i = lo; i < std::min(hi, n); i++) heap.push_back({0, (n - i + S - 1) / S, 0, i});
-            std::make_heap(heap.begin(), heap.end(), worse);
+            heap.clear();
+            used.assign(S, 0u);
+            for (uint32_t i = lo; i < std::min(hi, n); i++) heap.push_back((uint64_t)std::min((n - i + S - 1) / S, 0xffffu) << 16 | i);
+            std::make_heap(heap.begin(), heap.end(), std::greater<uint64_t>());
             uint64_t worst = 0;
             for (const piece &x : todo) {
                 if (heap.empty()) return ~0ull;                // more pieces than slots: not a plan
-                std::pop_heap(heap.begin(), heap.end(), worse);
-                simd_load &top = heap.back();
-                out[top.idx + top.used * S] = x;
-                top.used++; top.load += cost(x);
-                worst = std::max(worst, top.load);
-                if (top.used == top.slots) heap.pop_back(); else std::push_heap(heap.begin(), heap.end(), worse);
+                std::pop_heap(heap.begin(), heap.end(), std::greater<uint64_t>());
+                uint64_t &top = heap.back();
+                const uint32_t idx = (uint32_t)top & 0xffffu, slots = (n - idx + S - 1) / S;
+                out[idx + used[idx] * S] = x;
+                top += (uint64_t)cost(x) << 32;
+                worst = std::max(worst, top >> 32);
+                if (++used[idx] == slots) heap.pop_back(); else std::push_heap(heap.begin(), heap.end(), std::greater<uint64_t>());
             }
             return worst;
         };
@@ -1115,7 +1115,7 @@ static int plan_window(malcs_batch *b, int nlw, const std::vector<uint32_t> &pai
         }
         const uint32_t n = (uint32_t)todo.size();
         pieces.resize(n);
-        const uint64_t worst = deal(todo, 0, S, n, pieces);
+        bool dealt = false;
         // When n is not a multiple of S, r = n mod S SIMDs hold one piece more than the others, and with every tile cut in
         // the middle those SIMDs hold (q + 1) / q of the others' work: the launch waits for them (C2: 54 of 1 024 SIMDs
         // with four pieces of 13 blocks next to three of 15, 28.6 us for 100 000 pairs against 26.5 for 98 304).  A cut
@@ -1152,8 +1152,19 @@ static int plan_window(malcs_batch *b, int nlw, const std::vector<uint32_t> &pai
             std::vector<piece> alt(n);
             const uint64_t w0 = deal(minor, minor_a ? 0u : r, minor_a ? r : S, n, alt);
             const uint64_t w1 = deal(major, minor_a ? r : 0u, minor_a ? S : r, n, alt);
-            if (std::max(w0, w1) < worst) pieces.swap(alt);
+            // what the plain plan cannot beat: its fuller SIMDs hold q + 1 pieces, at best the smallest ones
+            std::vector<uint32_t> small;
+            for (uint32_t t = 0; t < std::min(n_tiles, q + 1u); t++) {
+                const uint32_t it = tile_iters[t] & 0x7fffffffu, c = middle(it);
+                small.push_back(c); small.push_back(it - c);
+            }
+            std::sort(small.begin(), small.end());
+            uint64_t bound = 0;
+            for (uint32_t k = 0; k <= q; k++) bound += small[k] * 12u;
+            if (std::max(w0, w1) <= bound || std::max(w0, w1) < deal(todo, 0, S, n, pieces)) pieces.swap(alt);
+            dealt = true;
         }
+        if (!dealt) deal(todo, 0, S, n, pieces);
     }
     const uint32_t n_pieces = (uint32_t)pieces.size();
     std::vector<uint32_t> piece_tab((size_t)4 * n_pieces + 1);      // off[n_pieces + 1], info, tile, join

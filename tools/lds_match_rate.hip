@@ -12,7 +12,10 @@
 #define CK(x) do{hipError_t e=(x); if(e!=hipSuccess){printf("HIP error %s at %d\n",hipGetErrorString(e),__LINE__);return 1;}}while(0)
 #define UA(U, V, P0, X0) "v_bitop3_b32 " U ", " V ", " P0 ", " X0 " bitop3:0x90\n\t"
 #define UB(U, P1, X1) "v_bitop3_b32 " U ", " U ", " P1 ", " X1 " bitop3:0x90\n\t"
-#define NX(V, U, S) "v_bitop3_b32 " V ", " U ", " S ", " V " bitop3:0xde\n\t"
+#define NX_(V, U, S, W) "v_bitop3_b32 " V ", " U ", " S ", " W " bitop3:0xde\n\t"
+#define NX3(V, U, S) NX_(V, U, S, V)
+#define GET_NX(_1, _2, _3, _4, NAME, ...) NAME
+#define NX(...) GET_NX(__VA_ARGS__, NX_, NX3)(__VA_ARGS__)
 #define AD0(S, O, V, U) "v_add_co_u32_e64 " S ", " O ", " V ", " U "\n\t"
 #define ADC(S, O, V, U, I) "v_addc_co_u32_e64 " S ", " O ", " V ", " U ", " I "\n\t"
 #define BFE2(s, A0, A1) "v_bfe_i32 " A0 ", v32, " #s ", 1\n\tv_bfe_i32 " A1 ", v36, " #s ", 1\n\t"
@@ -27,6 +30,25 @@
 #define LSTEP(s2, MN, M0, M1, I1, O1) LADDR(s2) LREAD(MN) "s_waitcnt lgkmcnt(7)\n\t" \
     "v_and_b32 v26, v24, " M1 "\n\tv_and_b32 v22, v20, " M0 "\n\t" \
     ADC("v27", "s[48:49]", "v24", "v26", I1) AD0("v23", O1, "v20", "v22") NX("v24", "v26", "v27") NX("v20", "v22", "v23")
+// variants of the LDS step, to price its parts in context: no LDS read; plain VOP2 additions; no address arithmetic
+#define LSTEP_NOREAD(s2, MN, M0, M1, I1, O1) LADDR(s2) \
+    "v_and_b32 v26, v24, " M1 "\n\tv_and_b32 v22, v20, " M0 "\n\t" \
+    ADC("v27", "s[48:49]", "v24", "v26", I1) AD0("v23", O1, "v20", "v22") NX("v24", "v26", "v27") NX("v20", "v22", "v23")
+#define LSTEP_ADD2(s2, MN, M0, M1, I1, O1) LADDR(s2) LREAD(MN) "s_waitcnt lgkmcnt(7)\n\t" \
+    "v_and_b32 v26, v24, " M1 "\n\tv_and_b32 v22, v20, " M0 "\n\t" \
+    "v_add_u32 v27, v24, v26\n\tv_add_u32 v23, v20, v22\n\t" NX("v24", "v26", "v27") NX("v20", "v22", "v23")
+#define LSTEP_NOADDR(s2, MN, M0, M1, I1, O1) LREAD(MN) "s_waitcnt lgkmcnt(7)\n\t" \
+    "v_and_b32 v26, v24, " M1 "\n\tv_and_b32 v22, v20, " M0 "\n\t" \
+    ADC("v27", "s[48:49]", "v24", "v26", I1) AD0("v23", O1, "v20", "v22") NX("v24", "v26", "v27") NX("v20", "v22", "v23")
+// the same eight VALU instructions and the read with no dependence between neighbours: results go to registers nothing reads
+#define LSTEP_INDEP(s2, MN, M0, M1, I1, O1) "v_bfe_u32 v62, v32, " #s2 ", 2\n\tv_lshl_or_b32 v62, v63, 9, v60\n\t" LREAD(MN) "s_waitcnt lgkmcnt(7)\n\t" \
+    "v_and_b32 v26, v24, " M1 "\n\tv_and_b32 v22, v20, " M0 "\n\t" \
+    ADC("v27", "s[48:49]", "v25", "v28", I1) AD0("v23", O1, "v21", "v29") NX("v34", "v38", "v39", "v33") NX("v40", "v41", "v42", "v43")
+#define L8X(S, a) \
+    S(a, "v[64:65]", "v64", "v65", "s[44:45]", "s[40:41]") S(a, "v[66:67]", "v66", "v67", "s[40:41]", "s[44:45]") \
+    S(a, "v[68:69]", "v68", "v69", "s[44:45]", "s[40:41]") S(a, "v[70:71]", "v70", "v71", "s[40:41]", "s[44:45]") \
+    S(a, "v[72:73]", "v72", "v73", "s[44:45]", "s[40:41]") S(a, "v[74:75]", "v74", "v75", "s[40:41]", "s[44:45]") \
+    S(a, "v[76:77]", "v76", "v77", "s[44:45]", "s[40:41]") S(a, "v[78:79]", "v78", "v79", "s[40:41]", "s[44:45]")
 #define L8(a) \
     LSTEP(a, "v[64:65]", "v64", "v65", "s[44:45]", "s[40:41]") LSTEP(a, "v[66:67]", "v66", "v67", "s[40:41]", "s[44:45]") \
     LSTEP(a, "v[68:69]", "v68", "v69", "s[44:45]", "s[40:41]") LSTEP(a, "v[70:71]", "v70", "v71", "s[40:41]", "s[44:45]") \
@@ -52,6 +74,10 @@ __global__ void __launch_bounds__(64) k(uint32_t *out, int blocks)
     for (int b = 0; b < blocks; b++) {
         if (MODE == 0) asm volatile(".p2align 3\n\ts_nop 0\n\t" X16(TWO_R) ::: CLOB);
         if (MODE == 1) asm volatile(".p2align 3\n\ts_nop 0\n\t" L8(0) L8(16) L8(4) L8(20) "s_waitcnt lgkmcnt(0)" ::: CLOB, "memory");
+        if (MODE == 2) asm volatile(".p2align 3\n\ts_nop 0\n\t" L8X(LSTEP_NOREAD, 0) L8X(LSTEP_NOREAD, 16) L8X(LSTEP_NOREAD, 4) L8X(LSTEP_NOREAD, 20) ::: CLOB, "memory");
+        if (MODE == 3) asm volatile(".p2align 3\n\ts_nop 0\n\t" L8X(LSTEP_ADD2, 0) L8X(LSTEP_ADD2, 16) L8X(LSTEP_ADD2, 4) L8X(LSTEP_ADD2, 20) "s_waitcnt lgkmcnt(0)" ::: CLOB, "memory");
+        if (MODE == 5) asm volatile(".p2align 3\n\ts_nop 0\n\t" "v_mov_b32 v61, v60\n\tv_mov_b32 v63, 1\n\t" L8X(LSTEP_INDEP, 0) L8X(LSTEP_INDEP, 16) L8X(LSTEP_INDEP, 4) L8X(LSTEP_INDEP, 20) "s_waitcnt lgkmcnt(0)" ::: CLOB, "v28", "v29", "v34", "v38", "v40", "v41", "v42", "v43", "v62", "v63", "memory");
+        if (MODE == 4) asm volatile(".p2align 3\n\ts_nop 0\n\t" "v_mov_b32 v61, v60\n\t" L8X(LSTEP_NOADDR, 0) L8X(LSTEP_NOADDR, 16) L8X(LSTEP_NOADDR, 4) L8X(LSTEP_NOADDR, 20) "s_waitcnt lgkmcnt(0)" ::: CLOB, "memory");
     }
     uint32_t r;
     asm volatile("v_xor_b32 %0, v20, v24" : "=v"(r) :: CLOB);
@@ -85,5 +111,9 @@ int main()
     CK(hipMalloc(&d, 4096 * 64 * 4));
     if (run<0>("planes folded (10 VALU per column)", 10, d)) return 1;
     if (run<1>("masks from LDS (8 VALU + ds_read_b64)", 8, d)) return 1;
+    if (run<2>("  the same without the LDS read", 8, d)) return 1;
+    if (run<3>("  the same with plain VOP2 additions", 8, d)) return 1;
+    if (run<4>("  the same without address arithmetic", 6, d)) return 1;
+    if (run<5>("  the same, no dependent neighbours", 8, d)) return 1;
     return 0;
 }
