@@ -15,6 +15,8 @@
 #include <atomic>
 #include <chrono>
 #include <deque>
+#include <memory>
+#include <mutex>
 #include <cstring>
 #include <new>
 #include <thread>
@@ -76,6 +78,43 @@ struct i64_store {
     }
 };
 
+// The int32 arrays of the graphs a worker thread built, back to back in blocks of raw memory (nothing is cleared: every
+// word is written by write_graph).  Blocks of the default size go back to a process-wide free list when the result
+// handle goes and are taken from there first: a batch of tandem-repeat windows writes a hundred megabytes of edges,
+// and fresh pages for them (first touch, sixteen threads at once) cost more than writing them.
+constexpr size_t I32_BLOCK = (size_t)1 << 22;             // words: 16 MB
+struct i32_blocks {
+    std::mutex lock;
+    std::vector<int32_t *> free_list;                      // I32_BLOCK words each, at most 32 (512 MB)
+    int32_t *get() { std::lock_guard<std::mutex> g(lock); if (free_list.empty()) return nullptr; int32_t *p = free_list.back(); free_list.pop_back(); return p; }
+    bool put(int32_t *p) { std::lock_guard<std::mutex> g(lock); if (free_list.size() >= 32) return false; free_list.push_back(p); return true; }
+    ~i32_blocks() { for (int32_t *p : free_list) delete[] p; }
+};
+i32_blocks &spare_i32_blocks() { static i32_blocks b; return b; }
+
+struct i32_store {
+    struct block { int32_t *p; size_t words; };
+    std::vector<block> blocks;
+    size_t used = 0;
+    i32_store() = default;
+    i32_store(const i32_store &) = delete;
+    i32_store &operator=(const i32_store &) = delete;
+    int32_t *take(size_t count)
+    {
+        if (blocks.empty() || used + count > blocks.back().words) {
+            int32_t *p = count <= I32_BLOCK ? spare_i32_blocks().get() : nullptr;
+            const size_t words = std::max(count, I32_BLOCK);
+            if (!p) p = new int32_t[words];
+            blocks.push_back({p, words});
+            used = 0;
+        }
+        int32_t *at = blocks.back().p + used;
+        used += count;
+        return at;
+    }
+    ~i32_store() { for (block &b : blocks) if (b.words != I32_BLOCK || !spare_i32_blocks().put(b.p)) delete[] b.p; }
+};
+
 struct pair_graph {
     int32_t status = MALCS_PAIR_OK;
     int64_t distance = 0;
@@ -86,14 +125,16 @@ struct pair_graph {
     i64_view edges;                 // 6 per edge
     std::vector<int64_t> canon;     // 4 per canonical variant (start, end, obs_from, obs_to), filled on demand
     bool canon_done = false;
-    // a graph the device built (malcs_gbuild.hip): int32 words as they came home, coordinates without the shift;
-    // `nodes` / `edges` above are filled from them when somebody asks for the arrays (widen())
+    // narrow: the graph's arrays as int32 words, coordinates without the shift (what malcs_graph_core.hpp writes, on the
+    // host or on the device: dev_built, malcs_gbuild.hip); `nodes` / `edges` above are filled from them when somebody
+    // needs the int64 arrays in place (widen()), the copy-out entry points widen on the way
+    bool narrow = false;
     const int32_t *dev_nodes = nullptr, *dev_edges = nullptr;
     const uint32_t *dev_runs = nullptr;      // its runs as the kernels left them (sorted, without the shift), 4 per run
     int64_t dev_n_nodes = 0, dev_n_edges = 0, dev_n_runs = 0, dev_shift = 0;
     bool dev_built = false;
-    size_t n_nodes() const { return dev_built ? (size_t)dev_n_nodes : nodes.size() / 3; }
-    size_t n_edges() const { return dev_built ? (size_t)dev_n_edges : edges.size() / 6; }
+    size_t n_nodes() const { return narrow ? (size_t)dev_n_nodes : nodes.size() / 3; }
+    size_t n_edges() const { return narrow ? (size_t)dev_n_edges : edges.size() / 6; }
     size_t n_runs() const { return dev_built ? (size_t)dev_n_runs : runs.size() / 4; }
 };
 
@@ -161,24 +202,22 @@ bool runs_from_events(event_span ev, int64_t m, int64_t n, std::vector<run> &out
 // The construction itself is malcs_graph_core.hpp (one source for this host path and for the device kernel of
 // malcs_gbuild.hip).  A worker thread keeps one arena and reuses it from pair to pair: no allocation per pair or node.
 struct builder {
-    std::vector<int32_t> node[9], edge[6], list[2], runs32;             // the arena's arrays, each its own vector
+    std::vector<int32_t> node[9], edge, list[2], runs32, where;      // the arena's arrays, each its own vector
     malcs_core::arena A;
     void bind()
     {
-        int32_t **n[9] = {&A.row, &A.col, &A.length, &A.wlen, &A.incoming, &A.head, &A.tail, &A.id, &A.order};
+        int32_t **n[9] = {&A.row, &A.col, &A.length, &A.wlen, &A.incoming, &A.deg, &A.tail, &A.id, &A.order};
         for (int k = 0; k < 9; k++) *n[k] = node[k].data();
-        int32_t **e[6] = {&A.e_child, &A.e_start, &A.e_end, &A.e_from, &A.e_to, &A.e_next};
-        for (int k = 0; k < 6; k++) *e[k] = edge[k].data();
-        A.node_cap = (int32_t)node[0].size(); A.edge_cap = (int32_t)edge[0].size(); A.list_cap = (int32_t)list[0].size();
+        A.edge = edge.data();
+        A.node_cap = (int32_t)node[0].size(); A.edge_cap = (int32_t)(edge.size() / 6); A.list_cap = (int32_t)list[0].size();
     }
     void start(int32_t nodes, int32_t edges, int32_t lists)
     {
         for (auto &v : node) if ((int32_t)v.size() < nodes) v.resize((size_t)nodes);
-        for (auto &v : edge) if ((int32_t)v.size() < edges) v.resize((size_t)edges);
+        if (edge.size() < 6 * (size_t)edges) edge.resize(6 * (size_t)edges);
         for (auto &v : list) if ((int32_t)v.size() < lists) v.resize((size_t)lists);
         // arrays grown for one graph stay for the next, all of a kind equally long
         for (auto &v : node) v.resize(node[0].size());
-        for (auto &v : edge) v.resize(edge[0].size());
         for (auto &v : list) v.resize(list[0].size());
         bind();
         A.cur = list[0].data(); A.below = list[1].data();
@@ -190,7 +229,7 @@ struct builder {
     {
         auto wider = [](std::vector<int32_t> &v) { if (v.size() > (size_t)1 << 29) return false; v.resize(v.size() * 2); return true; };
         if (which == malcs_core::GROW_NODES) { for (auto &v : node) if (!wider(v)) return false; }
-        else if (which == malcs_core::GROW_EDGES) { for (auto &v : edge) if (!wider(v)) return false; }
+        else if (which == malcs_core::GROW_EDGES) { if (edge.size() > (size_t)6 << 29 || !wider(edge)) return false; }
         else {
             const bool cur_is_0 = A.cur == list[0].data();
             for (auto &v : list) if (!wider(v)) return false;
@@ -201,8 +240,24 @@ struct builder {
     }
 };
 
-void build_graph(builder &B, i64_store &store, int64_t m, int64_t n, int64_t shift, const std::vector<run> &runs, int64_t n_levels,
-                 pair_graph &G)
+// builders outlive the call that made them: a worker thread takes one and gives it back
+struct builder_pool {
+    std::mutex lock;
+    std::vector<std::unique_ptr<builder>> spare;
+    std::unique_ptr<builder> get()
+    {
+        std::lock_guard<std::mutex> g(lock);
+        if (spare.empty()) return std::make_unique<builder>();
+        std::unique_ptr<builder> b = std::move(spare.back());
+        spare.pop_back();
+        return b;
+    }
+    void put(std::unique_ptr<builder> b) { std::lock_guard<std::mutex> g(lock); if (b && spare.size() < 64) spare.push_back(std::move(b)); }
+};
+builder_pool &spare_builders() { static builder_pool p; return p; }
+
+void build_graph(builder &B, i64_store &store, i32_store &narrow, int64_t m, int64_t n, int64_t shift, const std::vector<run> &runs,
+                 int64_t n_levels, pair_graph &G)
 {
     const bool degenerate = runs.empty() || n_levels == 0;
     if (degenerate) {                                                    // :370-377
@@ -232,14 +287,19 @@ void build_graph(builder &B, i64_store &store, int64_t m, int64_t n, int64_t shi
     malcs_core::build(A, (int32_t)m, (int32_t)n, shift, B.runs32.data(), R, (int32_t)n_levels, source, sink, sup,
                       [&B](malcs_core::arena &, int which) { return B.grow(which); });
     if (A.overflow) throw std::bad_alloc();                              // an array beyond 2^30 entries
-    int32_t n_edges = 0;
-    const int32_t count = malcs_core::number_nodes(A, source, n_edges);
-    G.nodes = store.take((size_t)count * 3);
-    G.edges = store.take((size_t)n_edges * 6);
-    malcs_core::write_graph<int64_t>(A, count, G.nodes.data(), G.edges.data(), shift);
+    int64_t n_edges = 0;
+    const int32_t count = malcs_core::count_reachable(A, source, n_edges);
+    if (n_edges > 0x7fffffffll / 6) throw std::bad_alloc();
+    int32_t *words = narrow.take((size_t)count * 3 + (size_t)n_edges * 6);
+    if (B.where.size() < (size_t)A.n_edges) B.where.resize((size_t)A.n_edges);
+    malcs_core::write_graph<int32_t>(A, source, words, words + (size_t)count * 3, 0, B.where.data());
+    G.narrow = true;
+    G.dev_nodes = words; G.dev_edges = words + (size_t)count * 3;
+    G.dev_n_nodes = count; G.dev_n_edges = n_edges; G.dev_shift = shift;
     G.supremal[0] = sup[0] + shift; G.supremal[1] = sup[1] + shift; G.supremal[2] = sup[2]; G.supremal[3] = sup[3];
     // a thread that has built one graph of a million edges does not keep 100 MB for the small ones that follow
-    if (B.edge[0].size() > ((size_t)1 << 22)) { for (auto &v : B.edge) { v.resize((size_t)1 << 22); v.shrink_to_fit(); } }
+    if (B.edge.size() > ((size_t)6 << 22)) { B.edge.resize((size_t)6 << 22); B.edge.shrink_to_fit(); }
+    if (B.where.size() > ((size_t)1 << 22)) { B.where.resize((size_t)1 << 22); B.where.shrink_to_fit(); }
     if (B.node[0].size() > ((size_t)1 << 20)) { for (auto &v : B.node) { v.resize((size_t)1 << 20); v.shrink_to_fit(); } for (auto &v : B.list) { v.resize((size_t)1 << 20); v.shrink_to_fit(); } }
 }
 
@@ -377,6 +437,7 @@ struct malcs_graphs {
     std::vector<pair_graph> g;
     sweep_set sweeps[4];
     std::deque<i64_store> stores;   // one per worker thread
+    std::deque<i32_store> narrow;   // likewise: the int32 arrays of the graphs built on the host
     std::deque<pinned_vec<int32_t>> dev_words;    // graphs the device built, one buffer per chunk of pairs
     float timing[4] = {0, 0, 0, 0};               // [3]: device graph construction (malcs_gbuild.hip)
     uint64_t n_dev_built = 0;
@@ -385,12 +446,14 @@ struct malcs_graphs {
 // the int64 arrays of a graph the device built (rows, columns and variant positions get their shift here)
 static void widen(malcs_graphs *g, pair_graph &G)
 {
-    if (!G.dev_built || G.nodes.p) return;
+    if (!G.narrow || G.nodes.p) return;
     if (g->stores.empty()) g->stores.resize(1);
-    G.runs = g->stores[0].take((size_t)G.dev_n_runs * 4);
-    for (int64_t r = 0; r < G.dev_n_runs; r++) {
-        G.runs[4 * r] = G.dev_runs[4 * r] + G.dev_shift; G.runs[4 * r + 1] = G.dev_runs[4 * r + 1] + G.dev_shift;
-        G.runs[4 * r + 2] = G.dev_runs[4 * r + 2]; G.runs[4 * r + 3] = G.dev_runs[4 * r + 3];
+    if (G.dev_built) {
+        G.runs = g->stores[0].take((size_t)G.dev_n_runs * 4);
+        for (int64_t r = 0; r < G.dev_n_runs; r++) {
+            G.runs[4 * r] = G.dev_runs[4 * r] + G.dev_shift; G.runs[4 * r + 1] = G.dev_runs[4 * r + 1] + G.dev_shift;
+            G.runs[4 * r + 2] = G.dev_runs[4 * r + 2]; G.runs[4 * r + 3] = G.dev_runs[4 * r + 3];
+        }
     }
     G.nodes = g->stores[0].take((size_t)G.dev_n_nodes * 3);
     G.edges = g->stores[0].take((size_t)G.dev_n_edges * 6);
@@ -484,6 +547,7 @@ static int gbuild_hook(void *user_, const malcs_sweep_chunk &c)
         G.dev_n_nodes = (int64_t)n_nodes; G.dev_n_edges = (int64_t)n_edges; G.dev_shift = sh;
         G.supremal[0] = po[3] + sh; G.supremal[1] = po[4] + sh; G.supremal[2] = po[5]; G.supremal[3] = po[6];
         G.dev_built = true;
+        G.narrow = true;
         u.out->n_dev_built++;
     }
     return MALCS_OK;
@@ -762,10 +826,12 @@ static int graph_batch(malcs_batch *b, const int64_t *shift, const int64_t *max_
     std::atomic<int> failed(0);
     std::atomic<uint64_t> ns_runs(0), ns_build(0);
     const bool trace = getenv("MALCS_TRACE") != nullptr;
-    auto worker = [&](i64_store *mine) {
+    auto worker = [&](i64_store *mine, i32_store *mine32) {
         i64_store &store = *mine;
         std::vector<run> runs;
-        builder B;
+        std::unique_ptr<builder> kept = spare_builders().get();       // arenas grown by earlier batches, pages touched
+        builder &B = *kept;
+        struct give_back { std::unique_ptr<builder> &b; ~give_back() { spare_builders().put(std::move(b)); } } back{kept};
         // pairs are taken in blocks: a block of small graphs costs about what the shared counter does, and a graph with
         // hundreds of thousands of edges ends the block that holds it
         const uint64_t block = N >= 4096 ? 64 : 1;
@@ -805,7 +871,7 @@ static int graph_batch(malcs_batch *b, const int64_t *shift, const int64_t *max_
                 if (runs[r].level < 0 || runs[r].level >= llcs) failed.store(1);
             }
             if (failed.load()) continue;
-            if (!G.dev_built) build_graph(B, store, m, n, sh, runs, runs.empty() ? 0 : llcs, G);
+            if (!G.dev_built) build_graph(B, store, *mine32, m, n, sh, runs, runs.empty() ? 0 : llcs, G);
             if (trace) { ns_runs += (uint64_t)((tb - ta) * 1e6); ns_build += (uint64_t)((now_ms() - tb) * 1e6); }
         }
     };
@@ -820,8 +886,9 @@ static int graph_batch(malcs_batch *b, const int64_t *shift, const int64_t *max_
     }
     std::vector<std::thread> pool;
     out->stores.resize(nt);
-    for (unsigned t = 1; t < nt; t++) pool.emplace_back(worker, &out->stores[t]);
-    worker(&out->stores[0]);
+    out->narrow.resize(nt);
+    for (unsigned t = 1; t < nt; t++) pool.emplace_back(worker, &out->stores[t], &out->narrow[t]);
+    worker(&out->stores[0], &out->narrow[0]);
     for (std::thread &t : pool) t.join();
     out->timing[2] = (float)(now_ms() - t0);
     stages.lap("host build");
@@ -916,7 +983,10 @@ int malcs_graphs_from_runs(uint64_t n_pairs, const int64_t *m, const int64_t *n,
     try {
         g->g.resize(n_pairs);
         g->stores.resize(1);
-        builder B;
+        g->narrow.resize(1);
+        std::unique_ptr<builder> kept = spare_builders().get();
+        builder &B = *kept;
+        struct give_back { std::unique_ptr<builder> &b; ~give_back() { spare_builders().put(std::move(b)); } } back{kept};
         std::vector<run> runs;
         for (uint64_t i = 0; i < n_pairs && rc == MALCS_OK; i++) {
             pair_graph &G = g->g[i];
@@ -943,7 +1013,7 @@ int malcs_graphs_from_runs(uint64_t n_pairs, const int64_t *m, const int64_t *n,
             for (size_t r = 0; r < runs.size(); r++) {
                 G.runs[4 * r] = runs[r].row + sh; G.runs[4 * r + 1] = runs[r].col + sh; G.runs[4 * r + 2] = runs[r].len; G.runs[4 * r + 3] = runs[r].level;
             }
-            build_graph(B, g->stores[0], m[i], n[i], sh, runs, runs.empty() ? 0 : n_levels[i], G);
+            build_graph(B, g->stores[0], g->narrow[0], m[i], n[i], sh, runs, runs.empty() ? 0 : n_levels[i], G);
         }
     } catch (const std::bad_alloc &) {
         malcs_set_error("out of host memory");
@@ -1015,14 +1085,31 @@ int malcs_graphs_runs(const malcs_graphs *g, uint64_t i, int64_t *dst)
     if (g && i < g->g.size()) widen(const_cast<malcs_graphs *>(g), const_cast<malcs_graphs *>(g)->g[i]);
     MALCS_COPY_OUT(runs)
 }
+// narrow graphs are widened on the way out (rows, columns and variant positions get their shift), not in place first
 int malcs_graphs_nodes(const malcs_graphs *g, uint64_t i, int64_t *dst)
 {
-    if (g && i < g->g.size()) widen(const_cast<malcs_graphs *>(g), const_cast<malcs_graphs *>(g)->g[i]);
+    if (g && i < g->g.size() && g->g[i].narrow && !g->g[i].nodes.p) {
+        const pair_graph &G = g->g[i];
+        if (!dst && G.dev_n_nodes) { malcs_set_error("bad argument"); return MALCS_ERR_ARG; }
+        for (int64_t v = 0; v < G.dev_n_nodes; v++) {
+            dst[3 * v] = G.dev_nodes[3 * v] + G.dev_shift; dst[3 * v + 1] = G.dev_nodes[3 * v + 1] + G.dev_shift; dst[3 * v + 2] = G.dev_nodes[3 * v + 2];
+        }
+        return MALCS_OK;
+    }
     MALCS_COPY_OUT(nodes)
 }
 int malcs_graphs_edges(const malcs_graphs *g, uint64_t i, int64_t *dst)
 {
-    if (g && i < g->g.size()) widen(const_cast<malcs_graphs *>(g), const_cast<malcs_graphs *>(g)->g[i]);
+    if (g && i < g->g.size() && g->g[i].narrow && !g->g[i].edges.p) {
+        const pair_graph &G = g->g[i];
+        if (!dst && G.dev_n_edges) { malcs_set_error("bad argument"); return MALCS_ERR_ARG; }
+        for (int64_t e = 0; e < G.dev_n_edges; e++) {
+            const int32_t *x = G.dev_edges + 6 * e;
+            int64_t *o = dst + 6 * e;
+            o[0] = x[0]; o[1] = x[1]; o[2] = x[2] + G.dev_shift; o[3] = x[3] + G.dev_shift; o[4] = x[4]; o[5] = x[5];
+        }
+        return MALCS_OK;
+    }
     MALCS_COPY_OUT(edges)
 }
 

@@ -8,6 +8,12 @@
 // of the sink :451, whose `max_sink` starts at 0 in SHIFTED coordinates -- a sink no edge ever reaches (identical
 // sequences given to LCSgraph() directly) ends up with a length that depends on the shift, so `build` takes it.
 //
+// Edge lists are persistent: an entry points at the entry appended before it (e_prev) and a node holds its newest
+// entry and its edge count, so splitting a node (:405-412, the split takes a copy of the parent's edges and both go on
+// growing) is two assignments -- parent and split share every entry that existed at the split, and entries never
+// change.  A 10 kb tandem-repeat window makes 400 000 to 900 000 edges out of some 50 000 entries this way; copying
+// them at every split was most of the construction's time and all of its memory.
+//
 // The working state lives in a caller-provided arena (LDS or global memory on the device, vectors on the host).  When
 // an array is full the caller's `grow(arena, which)` is asked for more room (the host re-allocates that array and
 // re-points the arena; the device has none to give and answers false); without more room `overflow` is set and the
@@ -23,14 +29,21 @@
 
 namespace malcs_core {
 
+#ifdef MALCS_CORE_STATS                  // tools/core_bench.cpp: dominance tests, list entries moved, levels with work
+extern long long stat_tests, stat_shift, stat_levels;
+#define MALCS_STAT(x) (x)
+#else
+#define MALCS_STAT(x) ((void)0)
+#endif
+
 struct arena {
-    // nodes (Node.row / .col / .length / ._length / ._incoming, lcs_graph.py:36-44); head / tail: first / last pool
-    // entry of the node's out-edges (append order = Node.edges order), -1: none
-    int32_t *row, *col, *length, *wlen, *incoming, *head, *tail;
+    // nodes (Node.row / .col / .length / ._length / ._incoming, lcs_graph.py:36-44); tail: newest pool entry of the
+    // node's out-edges (-1: none), deg: how many it has (Node.edges order = oldest first = the chain backwards)
+    int32_t *row, *col, *length, *wlen, *incoming, *deg, *tail;
     int32_t *id, *order;                 // numbering (after the build)
     int32_t node_cap, n_nodes;
-    // edge pool: child, variant (start, end, observed[from:to]), next entry of the same node
-    int32_t *e_child, *e_start, *e_end, *e_from, *e_to, *e_next;
+    // edge pool, 6 words per entry: child, variant (start, end, observed[from:to]), the entry appended before this one
+    int32_t *edge;
     int32_t edge_cap, n_edges;
     // the two level lists that are alive at a time
     int32_t *cur, *below;
@@ -47,16 +60,17 @@ MALCS_HD int64_t arena_words(int32_t node_cap, int32_t edge_cap, int32_t list_ca
 MALCS_HD void arena_bind(arena &A, int32_t *mem, int32_t node_cap, int32_t edge_cap, int32_t list_cap)
 {
     A.row = mem; A.col = A.row + node_cap; A.length = A.col + node_cap; A.wlen = A.length + node_cap;
-    A.incoming = A.wlen + node_cap; A.head = A.incoming + node_cap; A.tail = A.head + node_cap;
+    A.incoming = A.wlen + node_cap; A.deg = A.incoming + node_cap; A.tail = A.deg + node_cap;
     A.id = A.tail + node_cap; A.order = A.id + node_cap;
-    A.e_child = A.order + node_cap; A.e_start = A.e_child + edge_cap; A.e_end = A.e_start + edge_cap;
-    A.e_from = A.e_end + edge_cap; A.e_to = A.e_from + edge_cap; A.e_next = A.e_to + edge_cap;
-    A.cur = A.e_next + edge_cap; A.below = A.cur + list_cap;
+    A.edge = A.order + node_cap;
+    A.cur = A.edge + 6 * (int64_t)edge_cap; A.below = A.cur + list_cap;
     A.node_cap = node_cap; A.edge_cap = edge_cap; A.list_cap = list_cap;
     A.n_nodes = A.n_edges = A.n_cur = A.n_below = 0;
     A.overflow = 0;
 }
 
+enum { E_CHILD = 0, E_START = 1, E_END = 2, E_FROM = 3, E_TO = 4, E_PREV = 5, E_WORDS = 6 };
+constexpr int32_t E_COUNTED = (int32_t)0x80000000;        // on E_CHILD: count_reachable has been here
 enum { GROW_NODES = 0, GROW_EDGES = 1, GROW_LISTS = 2 };
 struct no_growth { MALCS_HD bool operator()(arena &, int) const { return false; } };
 
@@ -65,7 +79,7 @@ MALCS_HD int32_t add_node(arena &A, int32_t r, int32_t c, int32_t l, Grow &grow)
 {
     if (A.n_nodes >= A.node_cap && !(grow(A, GROW_NODES) && A.n_nodes < A.node_cap)) { A.overflow = 1; return A.node_cap - 1; }
     const int32_t v = A.n_nodes++;
-    A.row[v] = r; A.col[v] = c; A.length[v] = l; A.wlen[v] = l; A.incoming[v] = 0; A.head[v] = -1; A.tail[v] = -1;
+    A.row[v] = r; A.col[v] = c; A.length[v] = l; A.wlen[v] = l; A.incoming[v] = 0; A.deg[v] = 0; A.tail[v] = -1;
     return v;
 }
 
@@ -74,19 +88,10 @@ MALCS_HD void push_edge(arena &A, int32_t node, int32_t child, int32_t start, in
 {
     if (A.n_edges >= A.edge_cap && !(grow(A, GROW_EDGES) && A.n_edges < A.edge_cap)) { A.overflow = 1; return; }
     const int32_t slot = A.n_edges++;
-    A.e_child[slot] = child; A.e_start[slot] = start; A.e_end[slot] = end; A.e_from[slot] = from; A.e_to[slot] = to;
-    A.e_next[slot] = -1;
-    if (A.tail[node] < 0) A.head[node] = slot; else A.e_next[A.tail[node]] = slot;
+    int32_t *e = A.edge + E_WORDS * (int64_t)slot;
+    e[E_CHILD] = child; e[E_START] = start; e[E_END] = end; e[E_FROM] = from; e[E_TO] = to; e[E_PREV] = A.tail[node];
     A.tail[node] = slot;
-}
-
-template <typename Grow>
-MALCS_HD void copy_edges(arena &A, int32_t dst, int32_t src, Grow &grow)
-{
-    for (int32_t i = A.head[src]; i >= 0; i = A.e_next[i]) {
-        if (A.overflow) return;
-        push_edge(A, dst, A.e_child[i], A.e_start[i], A.e_end[i], A.e_from[i], A.e_to[i], grow);
-    }
+    A.deg[node]++;
 }
 
 // runs: 4 int32 per run {row, col, length, level}, sorted by (level, emission order); n_runs >= 1; n_levels = LLCS.
@@ -122,7 +127,7 @@ MALCS_HD void build(arena &A, int32_t m, int32_t n, int64_t shift, const int32_t
             int32_t stride = idle;
             if (n_cur == 1) {
                 const int32_t node = A.cur[0];
-                if (node != sink && A.head[node] < 0) { n_cur = 0; }
+                if (node != sink && A.tail[node] < 0) { n_cur = 0; }
                 else { stride = idle < A.wlen[node] - 1 ? idle : A.wlen[node] - 1; A.wlen[node] -= stride; }
             }
             if (stride > 0) { depth -= stride - 1; continue; }
@@ -134,11 +139,13 @@ MALCS_HD void build(arena &A, int32_t m, int32_t n, int64_t shift, const int32_t
         if (A.overflow) break;
         for (int32_t i = first; i < unread; i++) A.below[n_below++] = i;
         unread = first;
+        MALCS_STAT(stat_levels++);
         for (int32_t qi = 0; qi < n_cur && !A.overflow; qi++) {          // pop(0) in order, :390-391
             const int32_t node = A.cur[qi];
-            if (node != sink && A.head[node] < 0) continue;              // :393-394
+            if (node != sink && A.tail[node] < 0) continue;              // :393-394
             int32_t idx_parent = 0;
             const int32_t nr = A.row[node] + A.wlen[node], nc = A.col[node] + A.wlen[node];
+            MALCS_STAT(stat_tests += n_below);
             for (int32_t idx = 0; idx < n_below; idx++) {                // :397
                 const int32_t parent = A.below[idx];
                 const int32_t pr = A.row[parent] + A.wlen[parent], pc = A.col[parent] + A.wlen[parent];
@@ -147,7 +154,8 @@ MALCS_HD void build(arena &A, int32_t m, int32_t n, int64_t shift, const int32_t
                     if (A.incoming[parent] == depth) {                   // :405-412 split the parent
                         const int32_t split = add_node(A, A.row[parent], A.col[parent], A.length[parent], grow);
                         A.wlen[split] = A.wlen[parent];
-                        copy_edges(A, split, parent, grow);
+                        A.tail[split] = A.tail[parent];                  // the parent's edges so far, shared
+                        A.deg[split] = A.deg[parent];
                         push_edge(A, split, node, pr, nr - 1, pc, nc - 1, grow);               // :399-400
                         A.below[idx] = split;
                         A.row[parent] += A.wlen[parent];
@@ -163,6 +171,7 @@ MALCS_HD void build(arena &A, int32_t m, int32_t n, int64_t shift, const int32_t
                 A.wlen[node] -= 1;
                 if (idx_parent) A.incoming[node] = depth;
                 if (n_below >= A.list_cap && !(grow(A, GROW_LISTS) && n_below < A.list_cap)) { A.overflow = 1; break; }
+                MALCS_STAT(stat_shift += n_below - idx_parent);
                 for (int32_t k = n_below; k > idx_parent; k--) A.below[k] = A.below[k - 1];
                 A.below[idx_parent] = node;
                 n_below++;
@@ -179,7 +188,7 @@ MALCS_HD void build(arena &A, int32_t m, int32_t n, int64_t shift, const int32_t
     else source = add_node(A, 0, 0, 0, grow);
     for (int32_t qi = first; qi < n_cur; qi++) {                         // :434-445
         const int32_t node = A.cur[qi];
-        if (node != sink && A.head[node] < 0) continue;
+        if (node != sink && A.tail[node] < 0) continue;
         const int32_t nr = A.row[node] + A.wlen[node], nc = A.col[node] + A.wlen[node];
         if (A.row[source] < nr && A.col[source] < nc) {
             if (node == sink && nr - 1 + shift > max_sink) max_sink = nr - 1 + shift;
@@ -187,9 +196,12 @@ MALCS_HD void build(arena &A, int32_t m, int32_t n, int64_t shift, const int32_t
         }
     }
     int32_t source_offset = 0;                                           // :447-451
-    if (A.head[source] >= 0) {
-        source_offset = A.e_start[A.head[source]];
-        for (int32_t i = A.head[source]; i >= 0; i = A.e_next[i]) if (A.e_start[i] < source_offset) source_offset = A.e_start[i];
+    if (A.tail[source] >= 0) {
+        source_offset = A.edge[E_WORDS * (int64_t)A.tail[source] + E_START];
+        for (int32_t i = A.tail[source]; i >= 0; i = A.edge[E_WORDS * (int64_t)i + E_PREV]) {
+            const int32_t start = A.edge[E_WORDS * (int64_t)i + E_START];
+            if (start < source_offset) source_offset = start;
+        }
     }
     A.row[source] += source_offset;
     A.col[source] += source_offset;
@@ -202,39 +214,74 @@ MALCS_HD void build(arena &A, int32_t m, int32_t n, int64_t shift, const int32_t
     A.n_cur = n_cur; A.n_below = n_below;
 }
 
-// Canonical numbering: BFS by identity from the source, following edge order.  Fills A.id / A.order; returns the number
-// of nodes reached and, in n_edges, the number of edges leaving them.
-MALCS_HD int32_t number_nodes(arena &A, int32_t source, int32_t &n_edges)
+// The nodes the source reaches and the edges that leave them (any order; the chains are walked newest first, and only
+// as far as no walk has been before: what lies behind an entry lay behind it for every node that shares it).  Marks
+// the nodes in A.id (-2; others -1) for write_graph and the entries in their child word; uses A.order as the work list.
+MALCS_HD int32_t count_reachable(arena &A, int32_t source, int64_t &n_edges)
 {
     for (int32_t v = 0; v < A.n_nodes; v++) A.id[v] = -1;
     int32_t count = 0;
-    A.id[source] = 0;
+    A.id[source] = -2;
     A.order[count++] = source;
     n_edges = 0;
     for (int32_t h = 0; h < count; h++) {
-        for (int32_t i = A.head[A.order[h]]; i >= 0; i = A.e_next[i]) {
-            const int32_t child = A.e_child[i];
-            if (A.id[child] < 0) { A.id[child] = count; A.order[count++] = child; }
-            n_edges++;
+        const int32_t u = A.order[h];
+        n_edges += A.deg[u];
+        for (int32_t i = A.tail[u]; i >= 0;) {
+            int32_t *e = A.edge + E_WORDS * (int64_t)i;
+            const int32_t child = e[E_CHILD];
+            if (child < 0) break;
+            e[E_CHILD] = child | E_COUNTED;
+            if (A.id[child] == -1) { A.id[child] = -2; A.order[count++] = child; }
+            i = e[E_PREV];
         }
     }
     return count;
 }
 
-// nodes: 3 per node {row, col, length}; edges: 6 per edge {src, dst, start, end, obs_from, obs_to}, grouped by src in
-// node order and, within a node, in the order of Node.edges
+// Canonical numbering (BFS by identity from the source, following edge order) and the arrays in one pass, after
+// count_reachable.  nodes: 3 per node {row, col, length}; edges: 6 per edge {src, dst, start, end, obs_from, obs_to},
+// grouped by src in node order and, within a node, in the order of Node.edges.  A node's chain runs from its newest edge
+// to its oldest, so its edges are written from the back of their range; the children are numbered walking the range
+// forwards, each edge getting its child's number there (a child is numbered when an edge first leads to it).
+// `where` (optional: one word per pool entry, or null): the place in `edges` where an entry has been written.  The
+// chain behind an entry is the same for every node that shares it, so a walk that meets a written entry copies that
+// node's edges up to it (children numbered already, only the source differs) instead of walking on: every entry is
+// walked once, the rest is a block copy -- a tandem-repeat graph's 600 000 edges are 50 000 entries.
 template <typename T>
-MALCS_HD void write_graph(const arena &A, int32_t count, T *nodes, T *edges, int64_t shift)
+MALCS_HD void write_graph(arena &A, int32_t source, T *nodes, T *edges, int64_t shift, int32_t *where = nullptr)
 {
-    int32_t ei = 0;
-    for (int32_t h = 0; h < count; h++) {
-        const int32_t u = A.order[h];
+    if (where) for (int32_t i = 0; i < A.n_edges; i++) where[i] = -1;
+    int32_t seen = 0;
+    A.id[source] = 0;
+    A.order[seen++] = source;
+    int64_t ei = 0;
+    for (int32_t h = 0; h < seen; h++) {
+        const int32_t u = A.order[h], d = A.deg[u];
         nodes[3 * h] = (T)(A.row[u] + shift); nodes[3 * h + 1] = (T)(A.col[u] + shift); nodes[3 * h + 2] = (T)A.length[u];
-        for (int32_t i = A.head[u]; i >= 0; i = A.e_next[i]) {
-            T *o = edges + 6 * (int64_t)ei++;
-            o[0] = (T)h; o[1] = (T)A.id[A.e_child[i]]; o[2] = (T)(A.e_start[i] + shift); o[3] = (T)(A.e_end[i] + shift);
-            o[4] = (T)A.e_from[i]; o[5] = (T)A.e_to[i];
+        int32_t k = d, i = A.tail[u];                        // edges [k, d) of the node have been written from the chain
+        while (i >= 0 && !(where && where[i] >= 0)) {
+            const int32_t *e = A.edge + E_WORDS * (int64_t)i;
+            k--;
+            T *o = edges + 6 * (ei + k);
+            o[0] = (T)h; o[1] = (T)(e[E_CHILD] & ~E_COUNTED); o[2] = (T)(e[E_START] + shift); o[3] = (T)(e[E_END] + shift);
+            o[4] = (T)e[E_FROM]; o[5] = (T)e[E_TO];
+            if (where && ei + k <= 0x7fffffff) where[i] = (int32_t)(ei + k);
+            i = e[E_PREV];
         }
+        if (i >= 0) {                                        // a written entry: it is edge k - 1 here and there
+            const T *from = edges + 6 * ((int64_t)where[i] - (k - 1));
+            T *to = edges + 6 * ei;
+            __builtin_memcpy(to, from, sizeof(T) * 6 * (uint64_t)k);         // an earlier node's range: no overlap
+            for (int32_t s = 0; s < k; s++) to[6 * s] = (T)h;
+        }
+        T *o = edges + 6 * ei;
+        for (int32_t s = k; s < d; s++) {
+            const int32_t child = (int32_t)o[6 * s + 1];
+            if (A.id[child] < 0) { A.id[child] = seen; A.order[seen++] = child; }
+            o[6 * s + 1] = (T)A.id[child];
+        }
+        ei += d;
     }
 }
 

@@ -68,17 +68,16 @@ int main(int argc, char **argv)
             // retry with a larger arena (what the device does through the host), odd cases grow in the middle (the host)
             int32_t node_cap = 4, edge_cap = 4, list_cap = 2;
             for (;;) {
-                std::vector<int32_t> node[9], edge[6], list[2];
+                std::vector<int32_t> node[9], edge, list[2];
                 malcs_core::arena A;
                 auto bind = [&]() {
-                    int32_t **np[9] = {&A.row, &A.col, &A.length, &A.wlen, &A.incoming, &A.head, &A.tail, &A.id, &A.order};
+                    int32_t **np[9] = {&A.row, &A.col, &A.length, &A.wlen, &A.incoming, &A.deg, &A.tail, &A.id, &A.order};
                     for (int k = 0; k < 9; k++) *np[k] = node[k].data();
-                    int32_t **ep[6] = {&A.e_child, &A.e_start, &A.e_end, &A.e_from, &A.e_to, &A.e_next};
-                    for (int k = 0; k < 6; k++) *ep[k] = edge[k].data();
-                    A.node_cap = (int32_t)node[0].size(); A.edge_cap = (int32_t)edge[0].size(); A.list_cap = (int32_t)list[0].size();
+                    A.edge = edge.data();
+                    A.node_cap = (int32_t)node[0].size(); A.edge_cap = (int32_t)(edge.size() / 6); A.list_cap = (int32_t)list[0].size();
                 };
                 for (auto &v : node) v.assign((size_t)node_cap, 0);
-                for (auto &v : edge) v.assign((size_t)edge_cap, 0);
+                edge.assign(6 * (size_t)edge_cap, 0);
                 for (auto &v : list) v.assign((size_t)list_cap, 0);
                 bind();
                 A.cur = list[0].data(); A.below = list[1].data();
@@ -90,7 +89,7 @@ int main(int argc, char **argv)
                     malcs_core::build(A, (int32_t)m, (int32_t)n, shift, r32.data(), (int32_t)R, (int32_t)L, source, sink, s4,
                                       [&](malcs_core::arena &, int which) {
                                           if (which == malcs_core::GROW_NODES) for (auto &v : node) v.resize(v.size() * 2);
-                                          else if (which == malcs_core::GROW_EDGES) for (auto &v : edge) v.resize(v.size() * 2);
+                                          else if (which == malcs_core::GROW_EDGES) edge.resize(edge.size() * 2);
                                           else {
                                               const bool first = A.cur == list[0].data();
                                               for (auto &v : list) v.resize(v.size() * 2);
@@ -101,10 +100,10 @@ int main(int argc, char **argv)
                                       });
                 }
                 if (A.overflow) { node_cap *= 2; edge_cap *= 2; list_cap *= 2; continue; }
-                int32_t ne = 0;
-                const int32_t nn = malcs_core::number_nodes(A, source, ne);
+                int64_t ne = 0;
+                const int32_t nn = malcs_core::count_reachable(A, source, ne);
                 std::vector<int64_t> gn(3 * (size_t)nn + 1), ge(6 * (size_t)ne + 1);
-                malcs_core::write_graph<int64_t>(A, nn, gn.data(), ge.data(), shift);
+                malcs_core::write_graph<int64_t>(A, source, gn.data(), ge.data(), shift);
                 const bool same = nn == orc_graph_n_nodes(G) && ne == orc_graph_n_edges(G) && s4[0] + shift == sup[0] && s4[1] + shift == sup[1] &&
                                   s4[2] == sup[2] && s4[3] == sup[3] && !memcmp(gn.data(), nodes.data(), 3 * (size_t)nn * 8) &&
                                   !memcmp(ge.data(), edges.data(), 6 * (size_t)ne * 8);
