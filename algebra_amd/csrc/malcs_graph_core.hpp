@@ -242,9 +242,9 @@ MALCS_HD int32_t count_reachable(arena &A, int32_t source, int64_t &n_edges)
 // Canonical numbering (BFS by identity from the source, following edge order) and the arrays in one pass, after
 // count_reachable.  nodes: 3 per node {row, col, length}; edges: 6 per edge {src, dst, start, end, obs_from, obs_to},
 // grouped by src in node order and, within a node, in the order of Node.edges.  A node's chain runs from its newest edge
-// to its oldest, so its edges are written from the back of their range; the children are numbered walking the range
-// forwards, each edge getting its child's number there (a child is numbered when an edge first leads to it).
-// `where` (optional: one word per pool entry, or null): the place in `edges` where an entry has been written.  The
+// to its oldest; a child is numbered when an edge first leads to it, in edge order.
+// `where` (one word per pool entry; null: see below): the place in `edges` where an entry has been written.  A node's
+// edges are written from the back of their range walking the chain, then numbered walking the range forwards.  The
 // chain behind an entry is the same for every node that shares it, so a walk that meets a written entry copies that
 // node's edges up to it (children numbered already, only the source differs) instead of walking on: every entry is
 // walked once, the rest is a block copy -- a tandem-repeat graph's 600 000 edges are 50 000 entries.
@@ -259,14 +259,37 @@ MALCS_HD void write_graph(arena &A, int32_t source, T *nodes, T *edges, int64_t 
     for (int32_t h = 0; h < seen; h++) {
         const int32_t u = A.order[h], d = A.deg[u];
         nodes[3 * h] = (T)(A.row[u] + shift); nodes[3 * h + 1] = (T)(A.col[u] + shift); nodes[3 * h + 2] = (T)A.length[u];
+        if (!where) {
+            // No table: turn the chain round in place (oldest first), write and number along it, and turn every link
+            // back on the way -- two walks through the arena, nothing read back from `edges` (device memory there).
+            int32_t fwd = -1;
+            for (int32_t i = A.tail[u]; i >= 0;) {
+                int32_t *e = A.edge + E_WORDS * (int64_t)i;
+                const int32_t older = e[E_PREV];
+                e[E_PREV] = fwd; fwd = i; i = older;
+            }
+            T *o = edges + 6 * ei;
+            int32_t back = -1;
+            for (int32_t i = fwd; i >= 0; o += 6) {
+                int32_t *e = A.edge + E_WORDS * (int64_t)i;
+                const int32_t child = e[E_CHILD] & ~E_COUNTED;
+                if (A.id[child] < 0) { A.id[child] = seen; A.order[seen++] = child; }
+                o[0] = (T)h; o[1] = (T)A.id[child]; o[2] = (T)(e[E_START] + shift); o[3] = (T)(e[E_END] + shift);
+                o[4] = (T)e[E_FROM]; o[5] = (T)e[E_TO];
+                const int32_t newer = e[E_PREV];
+                e[E_PREV] = back; back = i; i = newer;
+            }
+            ei += d;
+            continue;
+        }
         int32_t k = d, i = A.tail[u];                        // edges [k, d) of the node have been written from the chain
-        while (i >= 0 && !(where && where[i] >= 0)) {
+        while (i >= 0 && where[i] < 0) {
             const int32_t *e = A.edge + E_WORDS * (int64_t)i;
             k--;
             T *o = edges + 6 * (ei + k);
             o[0] = (T)h; o[1] = (T)(e[E_CHILD] & ~E_COUNTED); o[2] = (T)(e[E_START] + shift); o[3] = (T)(e[E_END] + shift);
             o[4] = (T)e[E_FROM]; o[5] = (T)e[E_TO];
-            if (where && ei + k <= 0x7fffffff) where[i] = (int32_t)(ei + k);
+            if (ei + k <= 0x7fffffff) where[i] = (int32_t)(ei + k);
             i = e[E_PREV];
         }
         if (i >= 0) {                                        // a written entry: it is edge k - 1 here and there

@@ -103,7 +103,8 @@ int main(int argc, char **argv)
                 int64_t ne = 0;
                 const int32_t nn = malcs_core::count_reachable(A, source, ne);
                 std::vector<int64_t> gn(3 * (size_t)nn + 1), ge(6 * (size_t)ne + 1);
-                malcs_core::write_graph<int64_t>(A, source, gn.data(), ge.data(), shift);
+                std::vector<int32_t> where((size_t)A.n_edges + 1);                   // odd cases: with the table of written entries
+                malcs_core::write_graph<int64_t>(A, source, gn.data(), ge.data(), shift, c % 2 ? where.data() : nullptr);
                 const bool same = nn == orc_graph_n_nodes(G) && ne == orc_graph_n_edges(G) && s4[0] + shift == sup[0] && s4[1] + shift == sup[1] &&
                                   s4[2] == sup[2] && s4[3] == sup[3] && !memcmp(gn.data(), nodes.data(), 3 * (size_t)nn * 8) &&
                                   !memcmp(ge.data(), edges.data(), 6 * (size_t)ne * 8);
