@@ -651,16 +651,20 @@ __device__ __forceinline__ void diag_halves_lds(uint32_t (&V)[3], uint32_t (&P)[
     register uint32_t V0 asm("v21") = V[0], V1 asm("v24") = V[1];
     register uint32_t q0 asm("v44") = m1[0], q1 asm("v45") = m1[1], q2 asm("v46") = m1[2], q3 asm("v47") = m1[3];
     register uint32_t p0 asm("v28") = nxt[0], p1 asm("v29") = nxt[1], t0 asm("v32") = nxt[2], t1 asm("v36") = nxt[3];
-    register uint32_t base asm("v30") = (uint32_t)reinterpret_cast<uintptr_t>(tab) + lane * 4u;
+    // the stream puts a column's symbol into byte 1 of the address: the table must start at LDS address 0 (it is the
+    // kernel's only shared array)
+    if ((uint32_t)reinterpret_cast<uintptr_t>(tab) != 0u) __builtin_trap();
+    register uint32_t base asm("v30") = lane * 4u;
     uint32_t voff = lane * 4u, bank = ones;
     uint32_t cnt = (uint32_t)__builtin_amdgcn_readfirstlane(iters);
     asm volatile(DIAG_LDS_STREAM
                  : "+v"(V0), "+v"(V1), "+v"(q0), "+v"(q1), "+v"(q2), "+v"(q3), "+v"(p0), "+v"(p1), "+v"(t0), "+v"(t1),
                    [bank] "+&v"(bank), [voff] "+&v"(voff), [cnt] "+&s"(cnt), "+v"(base)   // early clobber: voff and base start equal
                  : [sbase] "s"(rows_u)
-                 : "v22", "v23", "v26", "v27", "v31", "v35", "v33", "v37", "v40", "v41", "v42", "v43", "v48", "v49", "v50", "v51",
+                 : "v22", "v23", "v26", "v27", "v31", "v35", "v33", "v37", "v38", "v39", "v53", "v54", "v40", "v41", "v42", "v43", "v48", "v49", "v50", "v51",
                    "v64", "v65", "v66", "v67", "v68", "v69", "v70", "v71", "v72", "v73", "v74", "v75", "v76", "v77", "v78", "v79",
-                   "s40", "s41", "s44", "s45", "s48", "s49", "scc", "memory");
+                   
+                   "s40", "s41", "s42", "s44", "s45", "s48", "s49", "scc", "memory");
     V[0] = V0; V[1] = V1;
     ones = bank;
 }
@@ -709,9 +713,18 @@ k_llcs_diag(const uint32_t *__restrict__ rows, const uint32_t *__restrict__ piec
             uint32_t *__restrict__ retry_list, const uint32_t *__restrict__ retry_first,
             const uint32_t *__restrict__ retry_cap, uint32_t *__restrict__ retry_count,
             uint32_t *__restrict__ retry_count_next, uint32_t n_classes,
-            uint32_t *__restrict__ join_buf)
+            uint32_t *__restrict__ join_buf, unsigned long long *__restrict__ stamps)
 {
     constexpr int T = 32 * NLW - 32;
+    // dev (MALCS_DIAG_STAMPS): the 100 MHz wall clock at four points of every wave + where it runs
+    auto stamp = [&](int k) {
+        if (stamps > reinterpret_cast<unsigned long long *>(1) && threadIdx.x == 0) {
+            unsigned long long t = wall_clock64();
+            if (k == 0) { uint32_t hw, xcc; asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hw)); asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc)); stamps[blockIdx.x * 6ull + 4] = hw; stamps[blockIdx.x * 6ull + 5] = (xcc & 15u) | ((unsigned long long)piece_info[blockIdx.x] << 8); }
+            stamps[blockIdx.x * 6ull + k] = t;
+        }
+    };
+    stamp(0);
     // the counters of the NEXT launch start at zero: nothing in flight reads or writes that set now
     if (blockIdx.x == 0 && threadIdx.x < n_classes) retry_count_next[threadIdx.x] = 0u;
     const unsigned lane = threadIdx.x;
@@ -746,6 +759,7 @@ k_llcs_diag(const uint32_t *__restrict__ rows, const uint32_t *__restrict__ piec
     rows_wait(nxt);
 
     uint32_t banked = 0;
+    stamp(1);
 
     // blocks [0, plain_hi) of a lane need no masks: all 32 columns exist and the leaving limb has no rows beyond the
     // matrix.  Rows above the matrix (V = 0 from the start, so they read as zero bits) all leave with the first three
@@ -761,11 +775,12 @@ k_llcs_diag(const uint32_t *__restrict__ rows, const uint32_t *__restrict__ piec
         if (halves) {                                  // every block of every lane is plain (the plan saw to that)
             uint32_t ones = 0;
             if (info & PIECE_CODES) {
-                __shared__ __attribute__((aligned(1024))) uint32_t lds_masks[16 * 64];
+                __shared__ __attribute__((aligned(4096))) uint32_t lds_masks[16 * 64];
                 diag_halves_lds(V, P, ones, rows_u + (META_ROWS + (NLW - 1) * NP) * 64, lane, nxt, iters, lds_masks);
             } else {
                 diag_halves_dna(V, P, ones, p, nxt, iters);
             }
+            stamp(2);
             if (info & PIECE_JOINED) {
                 // the window now holds rows [32 iters - kmax, + 64) (inside the matrix: the plan leaves two blocks on
                 // either side of a cut); `ones` = one bits of the rows that left.  The join needs 48 of the 64 rows and
@@ -867,11 +882,13 @@ k_llcs_diag(const uint32_t *__restrict__ rows, const uint32_t *__restrict__ piec
         d = (int32_t)(m + n - 2u * zeros);
     }
 
+    stamp(3);
     if (pid != 0xffffffffu && !skip) {
         if (d <= (halves ? MALCS_DIAG_HALF_T : T)) {
             dist[pid] = d;
         } else {
             const uint32_t cls = kc >> 16;
+            if (stamps == reinterpret_cast<unsigned long long *>(1)) return;      // dev (MALCS_DIAG_NORETRY): timing experiments with wrong results
             const uint32_t idx = atomicAdd(&retry_count[cls], 1u);
             if (idx < retry_cap[cls]) retry_list[retry_first[cls] + idx] = pid;
         }
@@ -879,7 +896,7 @@ k_llcs_diag(const uint32_t *__restrict__ rows, const uint32_t *__restrict__ piec
 }
 
 typedef void (*diag_kernel_t)(const uint32_t *, const uint32_t *, const uint32_t *, const uint32_t *, int32_t *, uint32_t *,
-                              const uint32_t *, const uint32_t *, uint32_t *, uint32_t *, uint32_t, uint32_t *);
+                              const uint32_t *, const uint32_t *, uint32_t *, uint32_t *, uint32_t, uint32_t *, unsigned long long *);
 template <int NP>
 diag_kernel_t pick_diag(int nlw)
 {
@@ -1254,8 +1271,19 @@ int malcs_diag_launch(malcs_batch *b, bool advance)
     if (ncls > 64) { malcs_set_error("too many retry classes"); return MALCS_ERR_INTERNAL; }
     if (advance) d.parity ^= 1u;
     uint32_t *cur = d.d_retry_count + d.parity * ncls, *next = d.d_retry_count + (d.parity ^ 1u) * ncls;
+    unsigned long long *stamps = nullptr;
+    const char *stamp_path = getenv("MALCS_DIAG_STAMPS");          // dev: per-wave time stamps of this launch into a file
+    if (getenv("MALCS_DIAG_NORETRY")) stamps = reinterpret_cast<unsigned long long *>(1);
+    else if (stamp_path && *stamp_path) { MALCS_HIP(hipMalloc((void **)&stamps, (size_t)d.n_pieces * 48)); MALCS_HIP(hipMemsetAsync(stamps, 0, (size_t)d.n_pieces * 48, st)); }
     hipLaunchKernelGGL(fn, dim3(d.n_pieces), dim3(64), 0, st, d.d_rows, d.d_piece_off, d.d_piece_info, d.d_piece_join, b->d_dist,
-                       d.d_retry_list, d.d_retry_first, d.d_retry_cap, cur, next, advance ? ncls : 0u, d.d_join_buf);
+                       d.d_retry_list, d.d_retry_first, d.d_retry_cap, cur, next, advance ? ncls : 0u, d.d_join_buf, stamps);
     MALCS_HIP(hipGetLastError());
+    if (stamps > reinterpret_cast<unsigned long long *>(1)) {
+        std::vector<unsigned long long> host((size_t)d.n_pieces * 6);
+        MALCS_HIP(hipStreamSynchronize(st));
+        MALCS_HIP(hipMemcpy(host.data(), stamps, host.size() * 8, hipMemcpyDeviceToHost));
+        MALCS_HIP(hipFree(stamps));
+        if (FILE *f = fopen(stamp_path, "wb")) { fwrite(host.data(), 8, host.size(), f); fclose(f); }
+    }
     return MALCS_OK;
 }

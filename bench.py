@@ -323,22 +323,52 @@ def main():
     e2e_s = (time.perf_counter() - t0) / reps
     assert np.array_equal(d_once, d)
 
-    # the relation matrix is a job of all ranks (sharded tiles + all-gather): every rank takes part
+    # the relation matrix is a job of all ranks (sharded tiles + all-gather): every rank takes part.  It runs beside the
+    # headline, which is measured by now: a failure or a hang there (the RCCL path has only ever run on one card before
+    # the driver's scaling run) is reported in the line instead of costing it.
     matrix = None
+    hung = False
     if not args.no_extra:
-        comm = gather = None
-        if world > 1 and args.backend == "nccl":
-            from algebra_amd import comm as job
-            comm = job.init(ctx, rank=rank, world=world)      # the library's own RCCL communicator (no torch in that path)
-        elif world > 1:
-            def gather(block):                                 # rehearsal on one card: gloo carries the label blocks
-                send = torch.from_numpy(np.ascontiguousarray(block))
-                recv = torch.empty((world * block.shape[0],) + tuple(block.shape[1:]), dtype=torch.uint8)
-                dist.all_gather_into_tensor(recv, send)
-                return recv.numpy()
-        matrix = relation_matrix(ctx, gen, rank, world, comm, gather, fence, all_max)
-        if comm is not None:
-            comm.close()
+        import threading
+        box = {}
+
+        def run_matrix():
+            try:
+                comm = gather = None
+                if world > 1 and args.backend == "nccl":
+                    # the library's own RCCL communicator (no torch in that path); its 128-byte id travels over the
+                    # process group this script has anyway
+                    uid = torch.zeros(128, dtype=torch.uint8, device="cuda")
+                    if rank == 0:
+                        uid.copy_(torch.frombuffer(bytearray(_native.comm_unique_id()), dtype=torch.uint8))
+                    dist.broadcast(uid, 0)
+                    comm = _native.Comm(ctx, bytes(uid.cpu().numpy().tobytes()), rank, world)
+                elif world > 1:
+                    def gather(block):                             # rehearsal on one card: gloo carries the label blocks
+                        send = torch.from_numpy(np.ascontiguousarray(block))
+                        recv = torch.empty((world * block.shape[0],) + tuple(block.shape[1:]), dtype=torch.uint8)
+                        dist.all_gather_into_tensor(recv, send)
+                        return recv.numpy()
+                box["matrix"] = relation_matrix(ctx, gen, rank, world, comm, gather, fence, all_max)
+                if comm is not None:
+                    comm.close()
+            except BaseException as e:                             # noqa: BLE001 -- reported, not raised
+                box["error"] = f"{type(e).__name__}: {e}"
+
+        if world == 1:
+            run_matrix()
+        else:
+            torch.cuda.set_device(local_rank)
+            worker = threading.Thread(target=lambda: (torch.cuda.set_device(local_rank), run_matrix()), daemon=True)
+            worker.start()
+            worker.join(float(os.environ.get("BENCH_MATRIX_TIMEOUT", "150")))
+            hung = worker.is_alive()
+            if hung:
+                box["error"] = "relation matrix did not finish in time (a rank failed or the all-gather hangs)"
+        matrix = box.get("matrix")
+        matrix_error = box.get("error")
+    else:
+        matrix_error = None
 
     if rank == 0:
         # HBM bytes per launch of that kernel: NOT measured in this run (counters need rocprofv3 passes of their own);
@@ -380,13 +410,18 @@ def main():
         if matrix is not None:
             out["relations_per_s"] = matrix["relations_per_s"]
             out["extra"] = {"c4_relation_matrix": matrix}
-        if world == 1 and not args.no_extra:
+        elif matrix_error is not None:
+            out["extra"] = {"c4_relation_matrix": {"error": matrix_error}}
+        if world == 1 and not args.no_extra and matrix is not None:
             out["extra"].update(extra_configs(ctx, _native, gen))
         if world == 1 and not args.no_cpu_baseline:                # rank 0 at N = 1 only
             out["cpu_baseline"] = cpu_baseline(data, cells / args.pairs)
             out["end_to_end"]["vs_cpu_port"] = round(out["end_to_end"]["pairs_per_s"] / out["cpu_baseline"]["pairs_per_s"], 2)
         print(json.dumps(out), flush=True)
 
+    if hung or (world > 1 and matrix_error is not None):
+        sys.stdout.flush()
+        os._exit(0)                                   # the headline stands; do not wait on a communicator that may never return
     batch.close()
     ctx.close()
     if dist is not None:

@@ -15,15 +15,18 @@ The stream, per block of 32 columns (i = block, e = i % 2; the loop body is an e
   middle  the window moves down 16 rows; masks of w[i+2] -> LDS, aligned slot i % 2 (w[i] is not read any more)
   half 1  16 columns on rows ((w[i+1]:w[i]) >> 16, (w[i+2]:w[i+1]) >> 16)   reads: shifted slots i % 2, (i + 1) % 2
   end     the window moves down 16 rows
-A column: v_bfe_u32 (the column's 2-bit symbol) + v_lshl_or_b32 (LDS address) + ds_read2st64_b32 (both limbs' masks)
-for the column LOOKAHEAD ahead, then per limb v_and_b32, v_add(c)_co_u32, v_bitop3_b32; limb 1 lags one column
+A column: v_and_b32_sdwa (the column's 2-bit symbol straight into byte 1 of the LDS address) + ds_read2st64_b32 (both
+limbs' masks) for the column LOOKAHEAD ahead, then per limb v_and_b32, v_add(c)_co_u32, v_bitop3_b32; limb 1 lags one column
 behind limb 0 as in the plane-folding stream, so the carry crosses between steps.
+Every block starts by setting the wave's priority to the number of blocks it has left, mod 4 (see set_priority).
 LDS of a wave: 16 rows of 64 dwords: row (ring * 2 + slot) * 4 + symbol, ring 0 = aligned, 1 = shifted by 16.
 """
 import os
 
-LOOKAHEAD = 6
-RING = 8                      # register pairs v[64:65] ... v[78:79]
+LOOKAHEAD = int(os.environ.get("GEN_LOOKAHEAD", "6"))
+RING = int(os.environ.get("GEN_RING", "8"))     # register pairs v[64:65] ... (v[78:79] for 8)
+SDWA = int(os.environ.get("GEN_SDWA", "1"))     # the symbol goes straight into byte 1 of the LDS address (one SDWA instruction per column)
+EXP = os.environ.get("GEN_EXP", "")             # timing experiments (wrong results): noread / nowrite / noaddr
 
 V0, V1 = "v21", "v24"
 U0, S0, U1, S1 = "v22", "v23", "v26", "v27"
@@ -33,10 +36,13 @@ TEXT = [("v32", "v36"), ("v33", "v37")]     # 2-bit symbols of columns 0-15 / 16
 PL0, PL1 = "v28", "v29"       # planes of the entering limb
 MASKS = [["v40", "v41", "v42", "v43"], ["v44", "v45", "v46", "v47"]]
 SHIFTED = ["v48", "v49", "v50", "v51"]
+SHT = ["v38", "v39", "v53"]    # the text word moved down by 2, 4, 6 bits
+THREE = "v54"
 CARRY = ["s[40:41]", "s[44:45]"]
 CARRY_TOP = "s[48:49]"
 
 
+PRIO = int(os.environ.get("GEN_PRIO", "1"))            # the wave's priority follows the blocks it has left
 ALIGN4 = int(os.environ.get("GEN_ALIGN4", "0"))       # keep 64-bit encodings at addresses = 4 (mod 8), see DESIGN section 4
 ALIGNED_KINDS = ("v_", "ds_")
 
@@ -54,6 +60,7 @@ def insn_size(s):
 
 
 def ring(col):
+    assert 32 % RING == 0 and RING >= LOOKAHEAD + 2     # the columns of a block are numbered from 0 again
     k = col % RING
     return f"v[{64 + 2 * k}:{65 + 2 * k}]", f"v{64 + 2 * k}", f"v{65 + 2 * k}"
 
@@ -77,30 +84,60 @@ class Stream:
         self.pos += size
 
     def ds(self, s):
+        if s.startswith("ds_write") and EXP in ("nowrite", "noread"):
+            if EXP == "noread":
+                self.emit(s)          # not counted: nothing waits for it
+            return
         self.emit(s)
         self.ds_issued += 1
 
     def wait_read(self, key):
         later = self.ds_issued - self.read_at.pop(key) - 1
         assert 0 <= later <= 15, later
-        self.emit(f"s_waitcnt lgkmcnt({later})")
+        if EXP != "noread":
+            self.emit(f"s_waitcnt lgkmcnt({later})")
+
+
+def text_of(e, G):
+    """Register and column (0 ... 15) inside it of column G (0 ... 31 this block of parity e, 32 ... the next block)."""
+    if G < 16:
+        return TEXT[e][0], G
+    if G < 32:
+        return TEXT[e][1], G - 16
+    return TEXT[1 - e][0], G - 32
 
 
 def read_column(st, e, G, key):
     """Issue the LDS read of column G (0 ... 31 this block of parity e, 32 ... the next block)."""
     if G < 16:
-        text, bit, lo, hi = TEXT[e][0], 2 * G, 4 * e, 4 * (1 - e)
+        lo, hi = 4 * e, 4 * (1 - e)             # aligned ring, slots i % 2 and (i + 1) % 2
     elif G < 32:
-        text, bit, lo, hi = TEXT[e][1], 2 * (G - 16), 8 + 4 * e, 8 + 4 * (1 - e)
+        lo, hi = 8 + 4 * e, 8 + 4 * (1 - e)     # shifted ring
     else:
-        text, bit, lo, hi = TEXT[1 - e][0], 2 * (G - 32), 4 * (1 - e), 4 * e
+        lo, hi = 4 * (1 - e), 4 * e
     a = ADDR[st.addr_turn]
     st.addr_turn ^= 1
     pair, _, _ = ring(G)
-    st.emit(f"v_bfe_u32 {a}, {text}, {bit}, 2")
-    st.emit(f"v_lshl_or_b32 {a}, {a}, 8, {BASE}")
+    text, k = text_of(e, G)
+    if EXP == "noaddr":
+        a = BASE
+    elif SDWA:
+        # Address = lane * 4 (byte 0, set once) | symbol << 8 (byte 1): the symbol of column k sits in the low bits of
+        # byte k / 4 of the text word moved down by 2 (k % 4) bits; three moved copies per word, made when its first
+        # column comes up.  One instruction per column where v_bfe_u32 + v_lshl_or_b32 are two.
+        if k == 0:
+            for j in (1, 2, 3):
+                st.emit(f"v_lshrrev_b32 {SHT[j - 1]}, {2 * j}, {text}")
+        src = text if k % 4 == 0 else SHT[k % 4 - 1]
+        st.emit(f"v_and_b32_sdwa {a}, {src}, {THREE} dst_sel:BYTE_1 dst_unused:UNUSED_PRESERVE src0_sel:BYTE_{k // 4} src1_sel:DWORD")
+    else:
+        st.emit(f"v_bfe_u32 {a}, {text}, {2 * k}, 2")
+        st.emit(f"v_lshl_or_b32 {a}, {a}, 8, {BASE}")
     st.read_at[key] = st.ds_issued
-    st.ds(f"ds_read2st64_b32 {pair}, {a} offset0:{lo} offset1:{hi}")
+    if EXP == "noread":
+        st.ds_issued += 1
+    else:
+        st.ds(f"ds_read2st64_b32 {pair}, {a} offset0:{lo} offset1:{hi}")
 
 
 def window_down(st):
@@ -110,8 +147,26 @@ def window_down(st):
     st.emit(f"v_alignbit_b32 {V1}, -1, {V1}, 16")
 
 
+def set_priority(st, e):
+    """Priority of the wave for this block = blocks it still has to do, mod 4: of the waves that share a SIMD the one
+    that is behind is served first (three blocks out of four when they are one block apart), so they finish together.
+    Left alone, the SIMD serves its oldest wave first, which then finishes a third ahead of the youngest and leaves it
+    to run the rest alone, at the rate of one wave (tools/diag_timeline.py)."""
+    st.emit("s_and_b32 s42, %[cnt], 3")
+    for k in (0, 1, 2):
+        st.emit(f"s_cmp_eq_u32 s42, {k}")
+        st.emit(f"s_cbranch_scc0 Ldiag_p{k}{e}%=")
+        st.emit(f"s_setprio {k}")
+        st.emit(f"s_branch Ldiag_pd{e}%=")
+        st.emit(f"Ldiag_p{k}{e}%=:")
+    st.emit("s_setprio 3")
+    st.emit(f"Ldiag_pd{e}%=:")
+
+
 def block(st, e, row_offset):
     new, prev = MASKS[e], MASKS[1 - e]
+    if PRIO:
+        set_priority(st, e)
     # masks of the entering limb: symbol = plane 0 bit | plane 1 bit << 1
     st.emit(f"v_and_b32 {new[3]}, {PL0}, {PL1}")
     st.emit(f"v_bitop3_b32 {new[0]}, {PL0}, {PL1}, {PL1} bitop3:0x03")
@@ -133,8 +188,8 @@ def block(st, e, row_offset):
             if s >= 1:
                 st.emit(f"v_and_b32 {U1}, {V1}, {ring(g - 1)[2]}")
             if s < 16:
-                if h == 1 and s == 16 - LOOKAHEAD:
-                    st.emit("s_waitcnt vmcnt(0)")           # the next block's text is read from here on
+                if h == 1 and s == 15 - LOOKAHEAD:
+                    st.emit("s_waitcnt vmcnt(0)")           # the next block's text is read from here on (the shift for its first pair)
                 read_column(st, e, g + LOOKAHEAD, ("n", g + LOOKAHEAD - 32) if g + LOOKAHEAD >= 32 else ("c", g + LOOKAHEAD))
             if s < 16:
                 st.wait_read(("c", g))
@@ -159,9 +214,14 @@ def block(st, e, row_offset):
 
 def generate():
     st = Stream()
+    if SDWA:
+        st.emit(f"v_mov_b32 {THREE}, 3")
+        st.emit(f"v_mov_b32 {ADDR[0]}, {BASE}")
+        st.emit(f"v_mov_b32 {ADDR[1]}, {BASE}")
     for g in range(LOOKAHEAD):
         read_column(st, 0, g, ("c", g))
     entry = {k: st.ds_issued - v for k, v in st.read_at.items()}
+    turn = st.addr_turn
     st.lines.append(".p2align 3")
     st.pos = 0
     st.emit("Ldiag_lds_loop%=:")
@@ -176,14 +236,17 @@ def generate():
     st.emit("s_cbranch_scc0 Ldiag_lds_loop%=")
     # the reads in flight at the end of either block were issued back to back, like the ones of the preamble
     assert {k: st.ds_issued - v for k, v in st.read_at.items()} == entry
+    assert st.addr_turn == turn
     st.emit("Ldiag_lds_done%=:")
+    if PRIO:
+        st.emit("s_setprio 0")
     st.emit("s_waitcnt vmcnt(0) lgkmcnt(0)")
     return st.lines
 
 
 def main():
     lines = generate()
-    out = os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "algebra_amd", "csrc", "malcs_diag_lds.inc")
+    out = os.environ.get("GEN_OUT") or os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "algebra_amd", "csrc", "malcs_diag_lds.inc")
     with open(out, "w") as f:
         f.write("// Generated by tools/gen_diag_lds.py -- do not edit.  The two-limb window stream with match masks from LDS\n")
         f.write(f"// (lookahead {LOOKAHEAD} columns, ring of {RING} register pairs); registers and operands: see diag_halves_lds.\n")
