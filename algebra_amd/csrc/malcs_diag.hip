@@ -729,11 +729,21 @@ k_llcs_diag(const uint32_t *__restrict__ rows, const uint32_t *__restrict__ piec
     if (blockIdx.x == 0 && threadIdx.x < n_classes) retry_count_next[threadIdx.x] = 0u;
     const unsigned lane = threadIdx.x;
     const uint32_t tile = blockIdx.x;
-    const uint32_t *rows_u = rows + (size_t)__builtin_amdgcn_readfirstlane(piece_off[tile]) * 64u;    // the piece's rows
+    // where the piece's rows are and what it is: two scalar loads side by side (the compiler makes them vector loads,
+    // at twice the latency, and everything a wave does waits for them)
+    uint32_t off_s, info;
+    {
+        const uint32_t t4 = (uint32_t)__builtin_amdgcn_readfirstlane((int)(tile * 4u));
+        asm volatile("s_load_dword %0, %2, %4\n\ts_load_dword %1, %3, %4\n\ts_waitcnt lgkmcnt(0)"
+                     : "=&s"(off_s), "=&s"(info) : "s"(piece_off), "s"(piece_info), "s"(t4));
+    }
+    const uint32_t *rows_u = rows + (size_t)off_s * 64u;                                               // the piece's rows
     const uint32_t *p = rows_u + lane;
-    const uint32_t info = __builtin_amdgcn_readfirstlane(piece_info[tile]);
     const int iters = (int)(info & PIECE_BLOCKS);
     const bool halves = NLW == 3 && NP == 2 && FUSED && (info & PIECE_HALF);     // two limbs, half-limb steps (T = 48)
+    // the rows of block 0 are asked for first, together with everything else a wave starts with: one trip to memory
+    uint32_t nxt[2 * NP];
+    rows_load_async(p + (META_ROWS + (NLW - 1) * NP) * 64, nxt, std::make_integer_sequence<int, 2 * NP>());
     const uint32_t pid = p[0], m = p[64], n = p[128], kc = p[192];
     const int kmax = (int)(kc & 0xffffu);          // block `it` = columns [32 it, 32 it + 32), its limb k = rows from 32 (it + k) - kmax
     p += META_ROWS * 64;
@@ -754,8 +764,6 @@ k_llcs_diag(const uint32_t *__restrict__ rows, const uint32_t *__restrict__ piec
         V[k] = rs >= 0 ? ~0u : (rs <= -32 ? 0u : (~0u << -rs));
     }
     p += (NLW - 1) * NP * 64;
-    uint32_t nxt[2 * NP];
-    rows_load_async(p, nxt, std::make_integer_sequence<int, 2 * NP>());
     rows_wait(nxt);
 
     uint32_t banked = 0;
@@ -885,7 +893,9 @@ k_llcs_diag(const uint32_t *__restrict__ rows, const uint32_t *__restrict__ piec
     stamp(3);
     if (pid != 0xffffffffu && !skip) {
         if (d <= (halves ? MALCS_DIAG_HALF_T : T)) {
-            dist[pid] = d;
+            // scattered by pair number: a line per lane.  Written through, the lines leave during the launch; left dirty
+            // in the L2s they are written back when the kernel ends, between this launch and the next
+            __builtin_nontemporal_store(d, &dist[pid]);
         } else {
             const uint32_t cls = kc >> 16;
             if (stamps == reinterpret_cast<unsigned long long *>(1)) return;      // dev (MALCS_DIAG_NORETRY): timing experiments with wrong results

@@ -48,3 +48,8 @@ for c in np.unique(cnt):
 late = np.argsort(-t[:, 3])[:8]
 for w in late:
     print(f"  late: wg {w} simd {w % S} blocks {blocks[w]} start {t[w,0]:.2f} loop {t[w,1]:.2f} -> {t[w,2]:.2f} done {t[w,3]:.2f} xcc {s[w,5] & 15} hw {s[w,4]:#x}")
+
+xcc = s[:, 5] & 15
+for x in range(8):
+    sel = xcc == x
+    print(f"  xcc {x}: {sel.sum()} waves, blocks {blocks[sel].sum()}, setup {np.median(t[sel,1]-t[sel,0]):.2f}, loop per block {np.median((t[sel,2]-t[sel,1])/blocks[sel]):.3f}, loop end median {np.median(t[sel,2]):.2f} max {t[sel,2].max():.2f}, done max {t[sel,3].max():.2f}")
