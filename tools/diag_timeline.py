@@ -53,3 +53,26 @@ xcc = s[:, 5] & 15
 for x in range(8):
     sel = xcc == x
     print(f"  xcc {x}: {sel.sum()} waves, blocks {blocks[sel].sum()}, setup {np.median(t[sel,1]-t[sel,0]):.2f}, loop per block {np.median((t[sel,2]-t[sel,1])/blocks[sel]):.3f}, loop end median {np.median(t[sel,2]):.2f} max {t[sel,2].max():.2f}, done max {t[sel,3].max():.2f}")
+
+# per CU: waves, blocks, when its last loop ends
+hw = s[:, 4]
+cu_key = (xcc << 16) | (hw & 0xff00)
+simd_id = (hw >> 4) & 3
+rows_ = []
+for key in np.unique(cu_key):
+    sel = cu_key == key
+    per_simd = [int(blocks[sel & (simd_id == q)].sum()) for q in range(4)]
+    rows_.append((int(sel.sum()), int(blocks[sel].sum()), max(per_simd), float(t[sel, 2].max()), float(np.median(t[sel, 2])), float(t[sel, 3].max())))
+rows_ = np.array(rows_)
+print(f"{len(rows_)} CUs")
+for w in np.unique(rows_[:, 0]):
+    sel = rows_[:, 0] == w
+    print(f"  CUs with {int(w)} waves: {sel.sum()}, blocks {rows_[sel,1].mean():.1f}, busiest SIMD {rows_[sel,2].mean():.1f} blocks, last loop end {rows_[sel,3].mean():.2f} (max {rows_[sel,3].max():.2f}), median loop end {rows_[sel,4].mean():.2f}")
+for b in np.unique(rows_[:, 1]):
+    sel = rows_[:, 1] == b
+    print(f"  CUs with {int(b)} blocks: {sel.sum()}, last loop end {rows_[sel,3].mean():.2f} (max {rows_[sel,3].max():.2f})")
+# do the workgroups w, w + 1024, ... really share a SIMD?
+same = 0
+for i in range(min(S, n - S)):
+    same += int(cu_key[i] == cu_key[i + S] and simd_id[i] == simd_id[i + S])
+print(f"workgroups w and w + {S} on the same SIMD: {same} of {min(S, n - S)}")
