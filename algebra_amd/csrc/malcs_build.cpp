@@ -256,8 +256,55 @@ struct builder_pool {
 };
 builder_pool &spare_builders() { static builder_pool p; return p; }
 
+// The copying of a large graph's shared edge prefixes (write_graph in two parts, malcs_graph_core.hpp), open to every
+// worker thread of the call: a tandem-repeat window's 900 000 edges are 50 000 pool entries, so building it is a
+// millisecond and writing it four, and the thread that got the largest graph of a batch would finish long after the
+// others.  Nodes are handed out in chunks through `next`.
+struct copy_job {
+    int32_t *edges = nullptr;
+    std::vector<int32_t> at, pre, from;
+    int32_t n_nodes = 0;
+    std::atomic<int32_t> next{0};
+    static constexpr int32_t CHUNK = 64;
+    bool help()                                              // one chunk; false: none left to take
+    {
+        const int32_t lo = next.fetch_add(CHUNK);
+        if (lo >= n_nodes) return false;
+        malcs_core::copy_prefixes<int32_t>(edges, at.data(), pre.data(), from.data(), lo, std::min(n_nodes, lo + CHUNK));
+        return true;
+    }
+};
+struct copy_jobs {
+    std::mutex lock;
+    std::vector<std::shared_ptr<copy_job>> open;
+    std::atomic<int> builders{0};                            // threads that may still add a job
+    void add(const std::shared_ptr<copy_job> &j) { std::lock_guard<std::mutex> g(lock); open.push_back(j); }
+    std::shared_ptr<copy_job> any()
+    {
+        std::lock_guard<std::mutex> g(lock);
+        while (!open.empty() && open.back()->next.load() >= open.back()->n_nodes) open.pop_back();
+        return open.empty() ? nullptr : open.back();
+    }
+    // after a thread's own pairs: copy for the others until nobody can add a job and none is open
+    void drain()
+    {
+        builders.fetch_sub(1);
+        for (;;) {
+            if (std::shared_ptr<copy_job> j = any()) { while (j->help()) {} continue; }
+            if (builders.load() <= 0) return;
+            std::this_thread::yield();
+        }
+    }
+};
+// graphs from this size on share their copying (MALCS_SHARED_COPY_EDGES moves the border: tests run both ways)
+int64_t shared_copy_edges()
+{
+    static const int64_t v = [] { const char *e = getenv("MALCS_SHARED_COPY_EDGES"); return e && *e ? atoll(e) : 100000ll; }();
+    return v;
+}
+
 void build_graph(builder &B, i64_store &store, i32_store &narrow, int64_t m, int64_t n, int64_t shift, const std::vector<run> &runs,
-                 int64_t n_levels, pair_graph &G)
+                 int64_t n_levels, pair_graph &G, copy_jobs *jobs = nullptr)
 {
     const bool degenerate = runs.empty() || n_levels == 0;
     if (degenerate) {                                                    // :370-377
@@ -292,7 +339,17 @@ void build_graph(builder &B, i64_store &store, i32_store &narrow, int64_t m, int
     if (n_edges > 0x7fffffffll / 6) throw std::bad_alloc();
     int32_t *words = narrow.take((size_t)count * 3 + (size_t)n_edges * 6);
     if (B.where.size() < (size_t)A.n_edges) B.where.resize((size_t)A.n_edges);
-    malcs_core::write_graph<int32_t>(A, source, words, words + (size_t)count * 3, 0, B.where.data());
+    if (jobs && n_edges >= shared_copy_edges()) {
+        std::shared_ptr<copy_job> j = std::make_shared<copy_job>();
+        j->edges = words + (size_t)count * 3;
+        j->n_nodes = count;
+        j->at.resize((size_t)count); j->pre.resize((size_t)count); j->from.resize((size_t)count);
+        malcs_core::write_graph_own<int32_t>(A, source, words, j->edges, 0, B.where.data(), j->at.data(), j->pre.data(), j->from.data());
+        jobs->add(j);
+        while (j->help()) {}                                 // with whoever else is free; chunks taken are finished before the call returns
+    } else {
+        malcs_core::write_graph<int32_t>(A, source, words, words + (size_t)count * 3, 0, B.where.data());
+    }
     G.narrow = true;
     G.dev_nodes = words; G.dev_edges = words + (size_t)count * 3;
     G.dev_n_nodes = count; G.dev_n_edges = n_edges; G.dev_shift = shift;
@@ -826,7 +883,12 @@ static int graph_batch(malcs_batch *b, const int64_t *shift, const int64_t *max_
     std::atomic<int> failed(0);
     std::atomic<uint64_t> ns_runs(0), ns_build(0);
     const bool trace = getenv("MALCS_TRACE") != nullptr;
+    copy_jobs jobs;
+    std::atomic<int> no_memory(0);
     auto worker = [&](i64_store *mine, i32_store *mine32) {
+        // whatever happens to this thread's pairs, it leaves through drain(): the others wait for that
+        struct leave { copy_jobs &j; ~leave() { j.drain(); } } on_exit{jobs};
+        try {
         i64_store &store = *mine;
         std::vector<run> runs;
         std::unique_ptr<builder> kept = spare_builders().get();       // arenas grown by earlier batches, pages touched
@@ -871,9 +933,10 @@ static int graph_batch(malcs_batch *b, const int64_t *shift, const int64_t *max_
                 if (runs[r].level < 0 || runs[r].level >= llcs) failed.store(1);
             }
             if (failed.load()) continue;
-            if (!G.dev_built) build_graph(B, store, *mine32, m, n, sh, runs, runs.empty() ? 0 : llcs, G);
+            if (!G.dev_built) build_graph(B, store, *mine32, m, n, sh, runs, runs.empty() ? 0 : llcs, G, &jobs);
             if (trace) { ns_runs += (uint64_t)((tb - ta) * 1e6); ns_build += (uint64_t)((now_ms() - tb) * 1e6); }
         }
+        } catch (const std::bad_alloc &) { no_memory.store(1); }
     };
     unsigned nt = std::min<unsigned>(16u, std::max(1u, std::thread::hardware_concurrency()));
     {
@@ -887,6 +950,7 @@ static int graph_batch(malcs_batch *b, const int64_t *shift, const int64_t *max_
     std::vector<std::thread> pool;
     out->stores.resize(nt);
     out->narrow.resize(nt);
+    jobs.builders.store((int)nt);
     for (unsigned t = 1; t < nt; t++) pool.emplace_back(worker, &out->stores[t], &out->narrow[t]);
     worker(&out->stores[0], &out->narrow[0]);
     for (std::thread &t : pool) t.join();
@@ -894,6 +958,7 @@ static int graph_batch(malcs_batch *b, const int64_t *shift, const int64_t *max_
     stages.lap("host build");
     if (trace) fprintf(stderr, "malcs host build: %llu pairs, %u threads, wall %.2f ms; summed over threads: events->runs %.2f ms, build_graph %.2f ms\n",
                        (unsigned long long)N, nt, out->timing[2], ns_runs.load() / 1e6, ns_build.load() / 1e6);
+    if (no_memory.load()) { malcs_set_error("out of host memory"); return MALCS_ERR_NOMEM; }
     if (failed.load()) { malcs_set_error("device events do not form runs (internal error)"); return MALCS_ERR_INTERNAL; }
     return MALCS_OK;
 }
@@ -988,6 +1053,7 @@ int malcs_graphs_from_runs(uint64_t n_pairs, const int64_t *m, const int64_t *n,
         builder &B = *kept;
         struct give_back { std::unique_ptr<builder> &b; ~give_back() { spare_builders().put(std::move(b)); } } back{kept};
         std::vector<run> runs;
+        copy_jobs jobs;                                      // this entry point builds on the calling thread alone
         for (uint64_t i = 0; i < n_pairs && rc == MALCS_OK; i++) {
             pair_graph &G = g->g[i];
             const int64_t sh = shift ? shift[i] : 0;
@@ -1013,7 +1079,7 @@ int malcs_graphs_from_runs(uint64_t n_pairs, const int64_t *m, const int64_t *n,
             for (size_t r = 0; r < runs.size(); r++) {
                 G.runs[4 * r] = runs[r].row + sh; G.runs[4 * r + 1] = runs[r].col + sh; G.runs[4 * r + 2] = runs[r].len; G.runs[4 * r + 3] = runs[r].level;
             }
-            build_graph(B, g->stores[0], g->narrow[0], m[i], n[i], sh, runs, runs.empty() ? 0 : n_levels[i], G);
+            build_graph(B, g->stores[0], g->narrow[0], m[i], n[i], sh, runs, runs.empty() ? 0 : n_levels[i], G, &jobs);
         }
     } catch (const std::bad_alloc &) {
         malcs_set_error("out of host memory");

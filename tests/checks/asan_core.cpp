@@ -104,6 +104,12 @@ int main(int argc, char **argv)
                 const int32_t nn = malcs_core::count_reachable(A, source, ne);
                 std::vector<int64_t> gn(3 * (size_t)nn + 1), ge(6 * (size_t)ne + 1);
                 std::vector<int32_t> where((size_t)A.n_edges + 1);                   // odd cases: with the table of written entries
+                if (c % 3 == 2) {                                                    // in two parts, the copies in two halves out of order
+                    std::vector<int32_t> at((size_t)nn + 1), pre((size_t)nn + 1), from((size_t)nn + 1);
+                    malcs_core::write_graph_own<int64_t>(A, source, gn.data(), ge.data(), shift, where.data(), at.data(), pre.data(), from.data());
+                    malcs_core::copy_prefixes<int64_t>(ge.data(), at.data(), pre.data(), from.data(), nn / 2, nn);
+                    malcs_core::copy_prefixes<int64_t>(ge.data(), at.data(), pre.data(), from.data(), 0, nn / 2);
+                } else
                 malcs_core::write_graph<int64_t>(A, source, gn.data(), ge.data(), shift, c % 2 ? where.data() : nullptr);
                 const bool same = nn == orc_graph_n_nodes(G) && ne == orc_graph_n_edges(G) && s4[0] + shift == sup[0] && s4[1] + shift == sup[1] &&
                                   s4[2] == sup[2] && s4[3] == sup[3] && !memcmp(gn.data(), nodes.data(), 3 * (size_t)nn * 8) &&

@@ -45,6 +45,20 @@ def test_build_graph_from_level_lists(name, fixture):
         res.close()
 
 
+def test_build_graph_two_part_write():
+    """Graphs from 100 000 edges on write their edges in two parts (the nodes' own edges, then the shared prefixes, which
+    the worker threads of a batch copy together: write_graph_own / copy_prefixes).  MALCS_SHARED_COPY_EDGES=0 sends every
+    fixture graph that way; the library reads the variable once, hence the process of its own."""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, MALCS_SHARED_COPY_EDGES="0")
+    done = subprocess.run([sys.executable, "-m", "pytest", "-x", "-q", os.path.abspath(__file__), "-k", "from_level_lists"],
+                          cwd=root, env=env, capture_output=True, text=True, timeout=600)
+    assert done.returncode == 0, done.stdout[-2000:] + done.stderr[-2000:]
+
+
 def test_build_graph_facade_name():
     # the reference's own use: tests/lcs/test_lcs_graph.py builds graphs from _lcs_nodes output
     from algebra_amd.lcs.lcs_graph import LCSgraph, _build_graph
