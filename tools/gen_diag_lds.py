@@ -26,6 +26,7 @@ import os
 LOOKAHEAD = int(os.environ.get("GEN_LOOKAHEAD", "6"))
 RING = int(os.environ.get("GEN_RING", "8"))     # register pairs v[64:65] ... (v[78:79] for 8)
 SDWA = int(os.environ.get("GEN_SDWA", "1"))     # the symbol goes straight into byte 1 of the LDS address (one SDWA instruction per column)
+NT = " nt" if int(os.environ.get("GEN_NT", "1")) else ""
 EXP = os.environ.get("GEN_EXP", "")             # timing experiments (wrong results): noread / nowrite / noaddr
 
 V0, V1 = "v21", "v24"
@@ -173,10 +174,11 @@ def block(st, e, row_offset):
     st.emit(f"v_xor_b32 {new[1]}, {PL0}, {new[3]}")
     st.emit(f"v_xor_b32 {new[2]}, {PL1}, {new[3]}")
     nt = TEXT[1 - e]
-    st.emit(f"global_load_dword {PL0}, %[voff], %[sbase] offset:{row_offset}")
-    st.emit(f"global_load_dword {PL1}, %[voff], %[sbase] offset:{row_offset + 256}")
-    st.emit(f"global_load_dword {nt[0]}, %[voff], %[sbase] offset:{row_offset + 512}")
-    st.emit(f"global_load_dword {nt[1]}, %[voff], %[sbase] offset:{row_offset + 768}")
+    # rows are read once per launch: marked non-temporal, so that they do not push the lines a wave starts with out of L2
+    st.emit(f"global_load_dword {PL0}, %[voff], %[sbase] offset:{row_offset}{NT}")
+    st.emit(f"global_load_dword {PL1}, %[voff], %[sbase] offset:{row_offset + 256}{NT}")
+    st.emit(f"global_load_dword {nt[0]}, %[voff], %[sbase] offset:{row_offset + 512}{NT}")
+    st.emit(f"global_load_dword {nt[1]}, %[voff], %[sbase] offset:{row_offset + 768}{NT}")
     for k in range(4):
         st.emit(f"v_alignbit_b32 {SHIFTED[k]}, {new[k]}, {prev[k]}, 16")
     slot = 8 + 4 * (1 - e)
