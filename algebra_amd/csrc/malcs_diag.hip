@@ -648,7 +648,7 @@ __device__ __forceinline__ void diag_halves_lds(uint32_t (&V)[3], uint32_t (&P)[
         tab[(4 + k) * 64 + lane] = m1[k];                                  //               slot 1: w[1]
         tab[(8 + k) * 64 + lane] = (m0[k] >> 16) | (m1[k] << 16);          // shifted ring, slot 0: (w[1]:w[0]) >> 16
     }
-    register uint32_t V0 asm("v21") = V[0], V1 asm("v24") = V[1];
+    register uint32_t V0 asm(DIAG_LDS_V0) = V[0], V1 asm(DIAG_LDS_V1) = V[1];
     register uint32_t q0 asm("v44") = m1[0], q1 asm("v45") = m1[1], q2 asm("v46") = m1[2], q3 asm("v47") = m1[3];
     register uint32_t p0 asm("v28") = nxt[0], p1 asm("v29") = nxt[1], t0 asm("v32") = nxt[2], t1 asm("v36") = nxt[3];
     // the stream puts a column's symbol into byte 1 of the address: the table must start at LDS address 0 (it is the

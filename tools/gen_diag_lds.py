@@ -29,8 +29,13 @@ SDWA = int(os.environ.get("GEN_SDWA", "1"))     # the symbol goes straight into 
 NT = " nt" if int(os.environ.get("GEN_NT", "1")) else ""
 EXP = os.environ.get("GEN_EXP", "")             # timing experiments (wrong results): noread / nowrite / noaddr
 
-V0, V1 = "v21", "v24"
-U0, S0, U1, S1 = "v22", "v23", "v26", "v27"
+ADD64 = int(os.environ.get("GEN_ADD64", "0"))   # experiment: one v_lshl_add_u64 per column (both limbs on the same column) instead of two carry-chained additions; measured 23.2 against 22.2 us per C2 launch, not adopted
+if ADD64:
+    V0, V1 = "v20", "v21"         # even-aligned pairs: V v[20:21], U v[22:23], S v[26:27]
+    U0, U1, S0, S1 = "v22", "v23", "v26", "v27"
+else:
+    V0, V1 = "v21", "v24"
+    U0, S0, U1, S1 = "v22", "v23", "v26", "v27"
 BASE = "v30"                  # lane * 4 (+ the table's LDS offset, a multiple of 1024)
 ADDR = ["v31", "v35"]
 TEXT = [("v32", "v36"), ("v33", "v37")]     # 2-bit symbols of columns 0-15 / 16-31 of an even / odd block
@@ -185,7 +190,20 @@ def block(st, e, row_offset):
     st.ds(f"ds_write2st64_b32 {BASE}, {SHIFTED[0]}, {SHIFTED[1]} offset0:{slot} offset1:{slot + 1}")
     st.ds(f"ds_write2st64_b32 {BASE}, {SHIFTED[2]}, {SHIFTED[3]} offset0:{slot + 2} offset1:{slot + 3}")
     for h in range(2):
-        for s in range(17):
+        for s in range(16 if ADD64 else 0):
+            # both limbs on column g: U = V & mask, S = V + U as one 64-bit addition (the carry between the limbs is
+            # inside it, the one out of the top is dropped), V' = S | (V ^ U)
+            g = 16 * h + s
+            if h == 1 and s == 15 - LOOKAHEAD:
+                st.emit("s_waitcnt vmcnt(0)")
+            read_column(st, e, g + LOOKAHEAD, ("n", g + LOOKAHEAD - 32) if g + LOOKAHEAD >= 32 else ("c", g + LOOKAHEAD))
+            st.wait_read(("c", g))
+            st.emit(f"v_and_b32 {U0}, {V0}, {ring(g)[1]}")
+            st.emit(f"v_and_b32 {U1}, {V1}, {ring(g)[2]}")
+            st.emit(f"v_lshl_add_u64 v[{S0[1:]}:{S1[1:]}], v[{V0[1:]}:{V1[1:]}], 0, v[{U0[1:]}:{U1[1:]}]")
+            st.emit(f"v_bitop3_b32 {V0}, {U0}, {S0}, {V0} bitop3:0xde")
+            st.emit(f"v_bitop3_b32 {V1}, {U1}, {S1}, {V1} bitop3:0xde")
+        for s in range(0 if ADD64 else 17):
             g = 16 * h + s
             if s >= 1:
                 st.emit(f"v_and_b32 {U1}, {V1}, {ring(g - 1)[2]}")
@@ -252,6 +270,7 @@ def main():
     with open(out, "w") as f:
         f.write("// Generated by tools/gen_diag_lds.py -- do not edit.  The two-limb window stream with match masks from LDS\n")
         f.write(f"// (lookahead {LOOKAHEAD} columns, ring of {RING} register pairs); registers and operands: see diag_halves_lds.\n")
+        f.write(f'#define DIAG_LDS_V0 "{V0}"\n#define DIAG_LDS_V1 "{V1}"\n')
         f.write("#define DIAG_LDS_STREAM \\\n")
         for i, line in enumerate(lines):
             end = "\\n\\t" if i + 1 < len(lines) else ""
