@@ -633,8 +633,11 @@ __device__ __forceinline__ void diag_halves_dna(uint32_t (&V)[3], uint32_t (&P)[
 // On entry: V[0 ... 1] / P[0 ... 1] the limbs the window starts with, nxt the rows of block 0 (they start at
 // rows_u + lane); `ones` collects the one bits of the rows that leave.  The arithmetic is that of diag_halves_dna.
 #include "malcs_diag_lds.inc"
+// join_slots: the tile's words in the join buffer when the piece is a part of a cut tile (joined), whose other part's
+// word comes back in `pre` if it was there DIAG_LDS_JOINPRE blocks before the end (else zero).
 __device__ __forceinline__ void diag_halves_lds(uint32_t (&V)[3], uint32_t (&P)[3][2], uint32_t &ones, const uint32_t *rows_u,
-                                                unsigned lane, const uint32_t (&nxt)[4], int iters, uint32_t *tab)
+                                                unsigned lane, const uint32_t (&nxt)[4], int iters, uint32_t *tab,
+                                                const unsigned long long *join_slots, bool joined, unsigned long long &pre)
 {
     auto masks = [](uint32_t p0, uint32_t p1, uint32_t (&mk)[4]) {
         mk[0] = ~(p0 | p1); mk[1] = p0 & ~p1; mk[2] = ~p0 & p1; mk[3] = p0 & p1;
@@ -657,16 +660,21 @@ __device__ __forceinline__ void diag_halves_lds(uint32_t (&V)[3], uint32_t (&P)[
     register uint32_t base asm("v30") = lane * 4u;
     uint32_t voff = lane * 4u, bank = ones;
     uint32_t cnt = (uint32_t)__builtin_amdgcn_readfirstlane(iters);
+    const uint32_t trig = (uint32_t)__builtin_amdgcn_readfirstlane(joined ? DIAG_LDS_JOINPRE : 0);   // cnt is never 0 at the start of a block
+    const uint32_t vj = lane * 8u;
+    unsigned long long got = 0ull;
     asm volatile(DIAG_LDS_STREAM
                  : "+v"(V0), "+v"(V1), "+v"(q0), "+v"(q1), "+v"(q2), "+v"(q3), "+v"(p0), "+v"(p1), "+v"(t0), "+v"(t1),
-                   [bank] "+&v"(bank), [voff] "+&v"(voff), [cnt] "+&s"(cnt), "+v"(base)   // early clobber: voff and base start equal
-                 : [sbase] "s"(rows_u)
+                   [bank] "+&v"(bank), [voff] "+&v"(voff), [cnt] "+&s"(cnt), "+v"(base),  // early clobber: voff and base start equal
+                   [pre] "+&v"(got)
+                 : [sbase] "s"(rows_u), [trig] "s"(trig), [vj] "v"(vj), [sj] "s"(join_slots)
                  : "v22", "v23", "v26", "v27", "v31", "v35", "v33", "v37", "v38", "v39", "v53", "v54", "v40", "v41", "v42", "v43", "v48", "v49", "v50", "v51",
                    "v64", "v65", "v66", "v67", "v68", "v69", "v70", "v71", "v72", "v73", "v74", "v75", "v76", "v77", "v78", "v79",
                    
                    "s40", "s41", "s42", "s44", "s45", "s48", "s49", "scc", "memory");
     V[0] = V0; V[1] = V1;
     ones = bank;
+    pre = got;
 }
 
 // The same for the other classes: loads the compiler does not see, and a wait statement that every
@@ -731,12 +739,16 @@ k_llcs_diag(const uint32_t *__restrict__ rows, const uint32_t *__restrict__ piec
     const uint32_t tile = blockIdx.x;
     // where the piece's rows are and what it is: two scalar loads side by side (the compiler makes them vector loads,
     // at twice the latency, and everything a wave does waits for them)
-    uint32_t off_s, info;
+    // (the slot of the join buffer too: read after the loop, it was two more trips to memory in a row -- the kernel
+    // argument, then the table -- at the end of every wave of a cut tile, before the swap could even leave)
+    uint32_t off_s, info, jt;
     {
         const uint32_t t4 = (uint32_t)__builtin_amdgcn_readfirstlane((int)(tile * 4u));
-        asm volatile("s_load_dword %0, %2, %4\n\ts_load_dword %1, %3, %4\n\ts_waitcnt lgkmcnt(0)"
-                     : "=&s"(off_s), "=&s"(info) : "s"(piece_off), "s"(piece_info), "s"(t4));
+        asm volatile("s_load_dword %0, %3, %6\n\ts_load_dword %1, %4, %6\n\ts_load_dword %2, %5, %6\n\ts_waitcnt lgkmcnt(0)"
+                     : "=&s"(off_s), "=&s"(info), "=&s"(jt) : "s"(piece_off), "s"(piece_info), "s"(piece_join), "s"(t4));
     }
+    // the tile's slots in the join buffer (one 64-bit word per lane); for a piece that is not joined: the first tile's, unused
+    const unsigned long long *const join_slots = reinterpret_cast<const unsigned long long *>(join_buf) + (size_t)((info & PIECE_JOINED) ? jt : 0u) * 64u;
     const uint32_t *rows_u = rows + (size_t)off_s * 64u;                                               // the piece's rows
     const uint32_t *p = rows_u + lane;
     const int iters = (int)(info & PIECE_BLOCKS);
@@ -782,9 +794,25 @@ k_llcs_diag(const uint32_t *__restrict__ rows, const uint32_t *__restrict__ piec
     if constexpr (NLW == 3 && NP == 2 && FUSED) {
         if (halves) {                                  // every block of every lane is plain (the plan saw to that)
             uint32_t ones = 0;
+            unsigned long long pre = 0ull;             // the other part's join word, if it was there shortly before the end
+            // the join's table (see there): entry (front nibble | back nibble << 4) = sum << 16 | largest prefix sum of
+            // the four steps front bit - back bit, lowest bit first.  Four entries per lane, worked out while the wave's
+            // first rows are on their way; a wave's LDS operations complete in order, so no barrier
+            __shared__ uint32_t join_tab[256];
+            if (info & PIECE_JOINED) {
+#pragma unroll
+                for (int j = 0; j < 4; j++) {
+                    const uint32_t idx = lane * 4u + (uint32_t)j;
+                    int t = 0, mp = 0;
+#pragma unroll
+                    for (int k = 0; k < 4; k++) { t += (int)((idx >> k) & 1u) - (int)((idx >> (4 + k)) & 1u); mp = max(mp, t); }
+                    join_tab[idx] = ((uint32_t)t << 16) | (uint32_t)mp;
+                }
+            }
             if (info & PIECE_CODES) {
                 __shared__ __attribute__((aligned(4096))) uint32_t lds_masks[16 * 64];
-                diag_halves_lds(V, P, ones, rows_u + (META_ROWS + (NLW - 1) * NP) * 64, lane, nxt, iters, lds_masks);
+                diag_halves_lds(V, P, ones, rows_u + (META_ROWS + (NLW - 1) * NP) * 64, lane, nxt, iters, lds_masks,
+                                join_slots, (info & PIECE_JOINED) != 0u, pre);
             } else {
                 diag_halves_dna(V, P, ones, p, nxt, iters);
             }
@@ -798,13 +826,15 @@ k_llcs_diag(const uint32_t *__restrict__ rows, const uint32_t *__restrict__ piec
                 // next launch.  (Round 2 began with three stores, a wait, an atomic add on a flag per tile and three
                 // loads: three round trips in a row at the end of every launch; a __threadfence() in place of the wait
                 // writes back and invalidates the whole L2 per wave, 35 -> 103 us.)
-                const uint32_t jt = __builtin_amdgcn_readfirstlane(piece_join[tile]);
                 const bool back = info & PIECE_BACK;
                 skip = true;
                 if (pid != 0xffffffffu) {
-                    unsigned long long *slot = reinterpret_cast<unsigned long long *>(join_buf) + (size_t)jt * 64u + lane;
+                    unsigned long long *slot = const_cast<unsigned long long *>(join_slots) + lane;
                     const uint64_t mv = (((uint64_t)V[1] << 32) | V[0]) & 0xffffffffffffull;
-                    const uint64_t theirs = __hip_atomic_exchange(slot, mv | ((uint64_t)(ones + 1u) << 48), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    // (per lane: the other part's swap is one instruction, but its 64 words need not land together)
+                    uint64_t theirs = pre;
+                    if (theirs == 0ull)
+                        theirs = __hip_atomic_exchange(slot, mv | ((uint64_t)(ones + 1u) << 48), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                     if (theirs != 0ull) {
                         __hip_atomic_store(slot, 0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                         const uint64_t ov = theirs & 0xffffffffffffull;
@@ -813,21 +843,34 @@ k_llcs_diag(const uint32_t *__restrict__ rows, const uint32_t *__restrict__ piec
                         const int S = 2 * kmax - (int)(n - m);                       // 47 or 48
                         const uint64_t A = ~Vf, B = ~Vb & ((1ull << S) - 1ull);
                         const uint64_t Br = __brevll(B) >> (64 - S);                 // bit x: row S - 1 - x of the back window
-                        const uint32_t a0 = (uint32_t)A, a1 = (uint32_t)(A >> 32), b0 = (uint32_t)Br, b1 = (uint32_t)(Br >> 32);
+                        const uint64_t Am = A & ((1ull << S) - 1ull);                // rows beyond S: no step
+                        const uint32_t a0 = (uint32_t)Am, a1 = (uint32_t)(Am >> 32), b0 = (uint32_t)Br, b1 = (uint32_t)(Br >> 32);
                         // x = 0: nothing of the front window, S rows of the back one; step x moves row x from the back
-                        // window's side to the front one's.  Three stretches of the walk side by side (total and largest
-                        // prefix of each): the wave is alone on its SIMD by now, and one chain of 48 steps would wait
-                        // for itself.
-                        int t0 = 0, t1 = 0, t2 = 0, m0 = 0, m1 = 0, m2 = 0;
+                        // window's side to the front one's: a walk of S steps of +1 / 0 / -1 whose largest prefix sum is
+                        // asked for.  Four steps at a time through join_tab (index: four bits of either side): the wave
+                        // is alone on its SIMD by now, where an instruction issues every five cycles or so, and a step
+                        // at a time the walk was 260 of them (0.7 us at the end of every launch).
+                        const uint32_t x0 = (a0 & 0x0f0f0f0fu) | ((b0 << 4) & 0xf0f0f0f0u);          // byte k: rows 8 k ... 8 k + 3
+                        const uint32_t y0 = ((a0 >> 4) & 0x0f0f0f0fu) | (b0 & 0xf0f0f0f0u);          //         rows 8 k + 4 ... 8 k + 7
+                        const uint32_t x1 = (a1 & 0x0f0fu) | ((b1 << 4) & 0xf0f0u);
+                        const uint32_t y1 = ((a1 >> 4) & 0x0f0fu) | (b1 & 0xf0f0u);
+                        uint32_t e[MALCS_DIAG_HALF_T / 4];
 #pragma unroll
-                        for (int x = 0; x < 16; x++) {
-                            t0 += (int)((a0 >> x) & 1u) - (int)((b0 >> x) & 1u); m0 = max(m0, t0);
-                            t1 += (int)((a0 >> (16 + x)) & 1u) - (int)((b0 >> (16 + x)) & 1u); m1 = max(m1, t1);
-                            if (x < MALCS_DIAG_HALF_T - 33) { t2 += (int)((a1 >> x) & 1u) - (int)((b1 >> x) & 1u); m2 = max(m2, t2); }
+                        for (int k = 0; k < 4; k++) {
+                            e[2 * k] = join_tab[(x0 >> (8 * k)) & 0xffu];
+                            e[2 * k + 1] = join_tab[(y0 >> (8 * k)) & 0xffu];
                         }
-                        int best = max(max(m0, t0 + m1), t0 + t1 + m2);
-                        if (S == MALCS_DIAG_HALF_T)                                  // x = 47
-                            best = max(best, t0 + t1 + t2 + (int)((a1 >> (MALCS_DIAG_HALF_T - 33)) & 1u) - (int)((b1 >> (MALCS_DIAG_HALF_T - 33)) & 1u));
+#pragma unroll
+                        for (int k = 0; k < MALCS_DIAG_HALF_T / 8 - 4; k++) {
+                            e[8 + 2 * k] = join_tab[(x1 >> (8 * k)) & 0xffu];
+                            e[9 + 2 * k] = join_tab[(y1 >> (8 * k)) & 0xffu];
+                        }
+                        int t = 0, best = 0;
+#pragma unroll
+                        for (int k = 0; k < MALCS_DIAG_HALF_T / 4; k++) {
+                            best = max(best, t + (int)(e[k] & 0xffffu));
+                            t += (int)e[k] >> 16;
+                        }
                         best += __popcll(B);
                         // zero bits of the rows that left either window (all inside the matrix but the kmax rows above it)
                         const uint32_t zeros = n - ones - oo - 2u * (uint32_t)kmax + (uint32_t)best;

@@ -27,7 +27,7 @@ LOOKAHEAD = int(os.environ.get("GEN_LOOKAHEAD", "6"))
 RING = int(os.environ.get("GEN_RING", "8"))     # register pairs v[64:65] ... (v[78:79] for 8)
 SDWA = int(os.environ.get("GEN_SDWA", "1"))     # the symbol goes straight into byte 1 of the LDS address (one SDWA instruction per column)
 NT = " nt" if int(os.environ.get("GEN_NT", "1")) else ""
-EXP = os.environ.get("GEN_EXP", "")             # timing experiments (wrong results): noread / nowrite / noaddr
+EXP = os.environ.get("GEN_EXP", "")             # timing experiments (wrong results): noread / nowrite / noaddr / noload / nowaitvm
 
 ADD64 = int(os.environ.get("GEN_ADD64", "0"))   # experiment: one v_lshl_add_u64 per column (both limbs on the same column) instead of two carry-chained additions; measured 23.2 against 22.2 us per C2 launch, not adopted
 if ADD64:
@@ -48,6 +48,7 @@ CARRY = ["s[40:41]", "s[44:45]"]
 CARRY_TOP = "s[48:49]"
 
 
+JOINPRE = int(os.environ.get("GEN_JOINPRE", "1"))      # the other part's join word is asked for when this many blocks are left (0: never)
 PRIO = int(os.environ.get("GEN_PRIO", "1"))            # the wave's priority follows the blocks it has left
 ALIGN4 = int(os.environ.get("GEN_ALIGN4", "0"))       # keep 64-bit encodings at addresses = 4 (mod 8), see DESIGN section 4
 ALIGNED_KINDS = ("v_", "ds_")
@@ -173,6 +174,14 @@ def block(st, e, row_offset):
     new, prev = MASKS[e], MASKS[1 - e]
     if PRIO:
         set_priority(st, e)
+    if JOINPRE:
+        # A part of a cut tile, JOINPRE blocks before its end: ask for the other part's word in the join buffer (agent
+        # scope).  If that part is done already, the word is here when the loop ends and this part joins without its own
+        # trip to memory (the swap); if not, it reads zero and swaps as before.  %[trig] = 0 for a piece that is no part.
+        st.emit("s_cmp_eq_u32 %[cnt], %[trig]")
+        st.emit(f"s_cbranch_scc0 Ldiag_nj{e}%=")
+        st.emit("global_load_dwordx2 %[pre], %[vj], %[sj] sc1")
+        st.emit(f"Ldiag_nj{e}%=:")
     # masks of the entering limb: symbol = plane 0 bit | plane 1 bit << 1
     st.emit(f"v_and_b32 {new[3]}, {PL0}, {PL1}")
     st.emit(f"v_bitop3_b32 {new[0]}, {PL0}, {PL1}, {PL1} bitop3:0x03")
@@ -180,10 +189,11 @@ def block(st, e, row_offset):
     st.emit(f"v_xor_b32 {new[2]}, {PL1}, {new[3]}")
     nt = TEXT[1 - e]
     # rows are read once per launch: marked non-temporal, so that they do not push the lines a wave starts with out of L2
-    st.emit(f"global_load_dword {PL0}, %[voff], %[sbase] offset:{row_offset}{NT}")
-    st.emit(f"global_load_dword {PL1}, %[voff], %[sbase] offset:{row_offset + 256}{NT}")
-    st.emit(f"global_load_dword {nt[0]}, %[voff], %[sbase] offset:{row_offset + 512}{NT}")
-    st.emit(f"global_load_dword {nt[1]}, %[voff], %[sbase] offset:{row_offset + 768}{NT}")
+    if EXP != "noload":
+        st.emit(f"global_load_dword {PL0}, %[voff], %[sbase] offset:{row_offset}{NT}")
+        st.emit(f"global_load_dword {PL1}, %[voff], %[sbase] offset:{row_offset + 256}{NT}")
+        st.emit(f"global_load_dword {nt[0]}, %[voff], %[sbase] offset:{row_offset + 512}{NT}")
+        st.emit(f"global_load_dword {nt[1]}, %[voff], %[sbase] offset:{row_offset + 768}{NT}")
     for k in range(4):
         st.emit(f"v_alignbit_b32 {SHIFTED[k]}, {new[k]}, {prev[k]}, 16")
     slot = 8 + 4 * (1 - e)
@@ -208,7 +218,7 @@ def block(st, e, row_offset):
             if s >= 1:
                 st.emit(f"v_and_b32 {U1}, {V1}, {ring(g - 1)[2]}")
             if s < 16:
-                if h == 1 and s == 15 - LOOKAHEAD:
+                if h == 1 and s == 15 - LOOKAHEAD and EXP != "nowaitvm":
                     st.emit("s_waitcnt vmcnt(0)")           # the next block's text is read from here on (the shift for its first pair)
                 read_column(st, e, g + LOOKAHEAD, ("n", g + LOOKAHEAD - 32) if g + LOOKAHEAD >= 32 else ("c", g + LOOKAHEAD))
             if s < 16:
@@ -270,7 +280,7 @@ def main():
     with open(out, "w") as f:
         f.write("// Generated by tools/gen_diag_lds.py -- do not edit.  The two-limb window stream with match masks from LDS\n")
         f.write(f"// (lookahead {LOOKAHEAD} columns, ring of {RING} register pairs); registers and operands: see diag_halves_lds.\n")
-        f.write(f'#define DIAG_LDS_V0 "{V0}"\n#define DIAG_LDS_V1 "{V1}"\n')
+        f.write(f'#define DIAG_LDS_V0 "{V0}"\n#define DIAG_LDS_V1 "{V1}"\n#define DIAG_LDS_JOINPRE {JOINPRE}\n')
         f.write("#define DIAG_LDS_STREAM \\\n")
         for i, line in enumerate(lines):
             end = "\\n\\t" if i + 1 < len(lines) else ""
