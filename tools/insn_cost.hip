@@ -47,6 +47,17 @@ __global__ void __launch_bounds__(256) k(uint32_t* out, int iters, unsigned long
         M(25, "v_or3_b32 v4, v5, v6, v7", "v_or3_b32 v8, v9, v10, v11", "v_or3_b32 v12, v13, v14, v15", "v_or3_b32 v16, v17, v18, v19")
         M(26, "v_bitop3_b32 v4, v5, v6, s50 bitop3:0x96", "v_bitop3_b32 v8, v9, v10, s51 bitop3:0x96", "v_bitop3_b32 v12, v13, v14, s50 bitop3:0x96", "v_bitop3_b32 v16, v17, v18, s51 bitop3:0x96")
         M(27, "v_bitop3_b32 v4, v5, v6, v6 bitop3:0x96", "v_bitop3_b32 v8, v9, v10, v10 bitop3:0x96", "v_bitop3_b32 v12, v13, v14, v14 bitop3:0x96", "v_bitop3_b32 v16, v17, v18, v18 bitop3:0x96")
+        M(28, "v_xor_b32 v4, v5, v6", "v_xor_b32 v8, v9, v10", "v_xor_b32 v12, v13, v14", "v_xor_b32 v16, v17, v18")
+        M(29, "v_or_b32 v4, v5, v6", "v_or_b32 v8, v9, v10", "v_or_b32 v12, v13, v14", "v_or_b32 v16, v17, v18")
+        M(30, "v_sub_u32 v4, v5, v6", "v_sub_u32 v8, v9, v10", "v_sub_u32 v12, v13, v14", "v_sub_u32 v16, v17, v18")
+        M(31, "v_lshlrev_b32 v4, 3, v6", "v_lshlrev_b32 v8, 3, v10", "v_lshlrev_b32 v12, 3, v14", "v_lshlrev_b32 v16, 3, v18")
+        M(32, "v_and_b32 v4, v5, v6", "v_add_u32 v8, v9, v10", "v_and_b32 v12, v13, v14", "v_add_u32 v16, v17, v18")
+        M(33, "v_and_b32 v4, v5, v6", "v_and_b32 v8, v9, v10", "v_add_u32 v12, v13, v14", "v_add_u32 v16, v17, v18")
+        M(34, "v_and_b32 v4, v5, v6", "v_bitop3_b32 v8, v9, v10, v11 bitop3:0x96", "v_and_b32 v12, v13, v14", "v_bitop3_b32 v16, v17, v18, v19 bitop3:0x96")
+        M(35, "v_and_b32 v4, v5, v6", "v_and_b32 v8, v9, v10", "v_bitop3_b32 v12, v13, v14, v15 bitop3:0x96", "v_bitop3_b32 v16, v17, v18, v19 bitop3:0x96")
+        M(36, "v_and_b32 v4, v5, v6", "v_lshrrev_b32 v8, 4, v9", "v_add_u32 v12, v13, v14", "v_bitop3_b32 v16, v17, v18, v19 bitop3:0x96")
+        M(37, "v_and_b32 v4, v5, v6\n v_and_b32 v8, v9, v10", "v_add_co_u32_e64 v12, s[42:43], v13, v14\n v_addc_co_u32_e64 v16, s[44:45], v17, v18, s[48:49]", "v_bitop3_b32 v20, v21, v22, v23 bitop3:0x96\n v_bitop3_b32 v4, v5, v6, v7 bitop3:0x96", "v_and_b32_sdwa v16, v17, v24 dst_sel:BYTE_1 dst_unused:UNUSED_PRESERVE src0_sel:BYTE_3 src1_sel:DWORD")
+        M(38, "v_and_b32 v4, v5, v6\n v_and_b32 v8, v9, v10", "v_add_u32 v12, v13, v14\n v_add_u32 v16, v17, v18", "v_bitop3_b32 v20, v21, v22, v23 bitop3:0x96\n v_bitop3_b32 v4, v5, v6, v7 bitop3:0x96", "v_and_b32 v16, v17, v24")
     }
     if (clk && blockIdx.x == 0 && threadIdx.x == 0) { clk[0] = clock64() - c0; clk[1] = wall_clock64() - w0; }
     out[blockIdx.x * blockDim.x + threadIdx.x] = threadIdx.x;
@@ -106,5 +117,16 @@ int main()
     if (run<25>("v_or3_b32")) return 1;
     if (run<26>("v_bitop3_b32 v, v, s")) return 1;
     if (run<27>("v_bitop3_b32 v, v, same v")) return 1;
+    if (run<28>("v_xor_b32")) return 1;
+    if (run<29>("v_or_b32")) return 1;
+    if (run<30>("v_sub_u32")) return 1;
+    if (run<31>("v_lshlrev_b32")) return 1;
+    if (run<32>("and add and add")) return 1;
+    if (run<33>("and and add add")) return 1;
+    if (run<34>("and bitop3 and bitop3")) return 1;
+    if (run<35>("and and bitop3 bitop3")) return 1;
+    if (run<36>("and lshr add bitop3 (all fast alone)")) return 1;
+    if (run<37>("column: 2 and, add_co, addc_co, 2 bitop3, sdwa (7 instructions: x 4/7)")) return 1;
+    if (run<38>("column without carries or sdwa (7 instructions: x 4/7)")) return 1;
     return 0;
 }

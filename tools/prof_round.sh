@@ -1,10 +1,30 @@
+# The round's profile passes over the bench (run on the GPU box: gpurun -- bash tools/prof_round.sh [TAG]); the summaries
+# are written on the box (the raw result databases of the counter passes are tens of megabytes) and come back under
+# gpurun_out/prof_<TAG>/: copy them into profiles/.
 set -e
+TAG=${1:-r02}
 cd /tmp && export TMPDIR=/tmp
 R=/root/repo
-rm -rf $R/gpurun_out/p2_*
-timeout -k 10 300 rocprofv3 --kernel-trace --stats -d $R/gpurun_out/p2_stats -o stats -- python3 $R/bench.py --steps 200 --warmup 20 --no-cpu-baseline --no-extra > $R/gpurun_out/p2_stats.log 2>&1
-timeout -s KILL 200 rocprofv3 --pmc FETCH_SIZE -d $R/gpurun_out/p2_fetch -o fetch -- python3 $R/bench.py --steps 20 --warmup 2 --no-cpu-baseline --no-extra > $R/gpurun_out/p2_fetch.log 2>&1
-timeout -s KILL 200 rocprofv3 --pmc WRITE_SIZE -d $R/gpurun_out/p2_write -o write -- python3 $R/bench.py --steps 20 --warmup 2 --no-cpu-baseline --no-extra > $R/gpurun_out/p2_write.log 2>&1
-timeout -s KILL 200 rocprofv3 --pmc SQ_WAVES SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY GRBM_GUI_ACTIVE -d $R/gpurun_out/p2_valu -o valu -- python3 $R/bench.py --steps 20 --warmup 2 --no-cpu-baseline --no-extra > $R/gpurun_out/p2_valu.log 2>&1
-tail -1 $R/gpurun_out/p2_stats.log | cut -c1-400
-timeout -s KILL 200 rocprofv3 --pmc SQ_INSTS_LDS SQ_ACTIVE_INST_LDS SQ_LDS_IDX_ACTIVE SQ_LDS_BANK_CONFLICT SQ_WAIT_INST_LDS SQ_WAVE_CYCLES SQ_INSTS_VALU SQ_WAIT_ANY -d $R/gpurun_out/p2_lds -o lds -- python3 $R/bench.py --steps 20 --warmup 2 --no-cpu-baseline --no-extra > $R/gpurun_out/p2_lds.log 2>&1
+P=$R/gpurun_out/raw_prof
+rm -rf $P $R/gpurun_out/prof_$TAG; mkdir -p $P $R/gpurun_out/prof_$TAG
+B="python3 $R/bench.py --no-cpu-baseline --no-extra"
+timeout -k 10 300 rocprofv3 --kernel-trace --stats -d $P/stats -o stats -- $B --steps 200 --warmup 20 > $P/stats.log 2>&1
+timeout -s KILL 200 rocprofv3 --pmc FETCH_SIZE -d $P/fetch -o fetch -- $B --steps 20 --warmup 2 > $P/fetch.log 2>&1
+timeout -s KILL 200 rocprofv3 --pmc WRITE_SIZE -d $P/write -o write -- $B --steps 20 --warmup 2 > $P/write.log 2>&1
+timeout -s KILL 200 rocprofv3 --pmc SQ_WAVES SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY GRBM_GUI_ACTIVE -d $P/valu -o valu -- $B --steps 20 --warmup 2 > $P/valu.log 2>&1
+timeout -s KILL 200 rocprofv3 --pmc SQ_INSTS_LDS SQ_ACTIVE_INST_LDS SQ_LDS_IDX_ACTIVE SQ_LDS_BANK_CONFLICT SQ_WAIT_INST_LDS SQ_WAVE_CYCLES SQ_INSTS_VALU SQ_WAIT_ANY -d $P/lds -o lds -- $B --steps 20 --warmup 2 > $P/lds.log 2>&1
+cd $R
+python3 tools/prof_summary.py $TAG $P/stats $P/fetch $P/write "$B --steps 200 --warmup 20 (stats) / --steps 20 --warmup 2 (FETCH_SIZE and WRITE_SIZE, a pass each)" > /dev/null
+python3 tools/valu_summary.py $TAG $P/valu "rocprofv3 --pmc SQ_WAVES SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY GRBM_GUI_ACTIVE -- $B --steps 20 --warmup 2" > /dev/null
+python3 - $TAG $P/lds "$B" <<'PY'
+import glob, json, sqlite3, sys
+tag, path, cmd = sys.argv[1:4]
+db = sqlite3.connect(glob.glob(path + "/**/*.db", recursive=True)[0])
+rows = db.execute("select counter_name, avg(value) from counters_collection where kernel_name like '%k_llcs_diag%' group by counter_name").fetchall()
+json.dump({"command": "rocprofv3 --pmc SQ_INSTS_LDS SQ_ACTIVE_INST_LDS SQ_LDS_IDX_ACTIVE SQ_LDS_BANK_CONFLICT SQ_WAIT_INST_LDS SQ_WAVE_CYCLES SQ_INSTS_VALU SQ_WAIT_ANY -- " + cmd + " --steps 20 --warmup 2",
+           "kernel": "k_llcs_diag<3,2,true>", "per_launch": dict(rows)}, open(f"profiles/{tag}_lds.json", "w"), indent=1)
+PY
+cp profiles/${TAG}_bench_stats.txt profiles/${TAG}_pmc.json profiles/${TAG}_valu.json profiles/${TAG}_lds.json gpurun_out/prof_$TAG/
+grep "^{" $P/stats.log > gpurun_out/prof_$TAG/bench_line_under_stats.json || true
+rm -rf $P
+head -6 profiles/${TAG}_bench_stats.txt
