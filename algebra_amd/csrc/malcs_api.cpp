@@ -183,8 +183,21 @@ void malcs_pool_trim(malcs_ctx *c)
 }
 
 // everything a context owns, released in reverse order of creation (also on the error paths of malcs_ctx_create)
+malcs_workers *malcs_ctx_workers(malcs_ctx *ctx)
+{
+    if (!ctx->workers) {
+        int threads = 16;
+        if (const char *e = getenv("MALCS_PACK_THREADS")) threads = std::max(1, atoi(e));
+        threads = std::min<int>(threads, (int)std::max(1u, std::thread::hardware_concurrency()));
+        ctx->workers = new malcs_workers(threads);
+    }
+    return ctx->workers;
+}
+
 static void ctx_release(malcs_ctx *c)
 {
+    delete c->workers;
+    c->workers = nullptr;
     for (malcs_batch *b : c->spare_batches) delete b;
     c->spare_batches.clear();
     malcs_pool_trim(c);
@@ -330,27 +343,89 @@ static int batch_build(malcs_ctx *ctx, const uint8_t *syms, const uint8_t *d_sym
     // ---- where every sequence goes in the arena ----------------------------------------------------------
     std::vector<uint64_t> &seq_byte_off = ctx->seq_byte_off;
     std::vector<uint32_t> &seq_len = ctx->seq_len, &seq_blk_off = ctx->seq_blk_off;
-    seq_byte_off.clear(); seq_len.clear(); seq_blk_off.clear();
     uint64_t total_blocks = 0;
+    bool placed = false;
     b->a_off.resize(n_pairs); b->a_len.resize(n_pairs); b->b_off.resize(n_pairs); b->b_len.resize(n_pairs);
     b->max_len = 0;
-    {
+    const bool threaded = n_pairs >= 16384 && syms != nullptr;
+    auto report_bad = [&]() -> int {                             // names the first sequence that is not inside the symbol buffer
+        for (uint64_t i = 0; i < n_pairs; i++) {
+            const bool bad_a = a_off[i] > n_syms || (uint64_t)a_len[i] > n_syms - a_off[i];
+            const bool bad_b = b_off[i] > n_syms || (uint64_t)b_len[i] > n_syms - b_off[i];
+            if (!bad_a && !bad_b) continue;
+            malcs_set_error("sequence [%llu,+%u) outside the symbol buffer of %llu bytes", (unsigned long long)(bad_a ? a_off[i] : b_off[i]),
+                            bad_a ? a_len[i] : b_len[i], (unsigned long long)n_syms);
+            return MALCS_ERR_ARG;
+        }
+        return MALCS_OK;
+    };
+    if (!threaded) {                                             // (large batches: checked by the threaded pass below)
         uint64_t bad = 0;                                        // every sequence inside the symbol buffer?
         for (uint64_t i = 0; i < n_pairs; i++)
             bad |= (uint64_t)(a_off[i] > n_syms) | (uint64_t)((uint64_t)a_len[i] > n_syms - a_off[i]) |
                    (uint64_t)(b_off[i] > n_syms) | (uint64_t)((uint64_t)b_len[i] > n_syms - b_off[i]);
-        if (bad) {
-            for (uint64_t i = 0; i < n_pairs; i++) {
-                const bool bad_a = a_off[i] > n_syms || (uint64_t)a_len[i] > n_syms - a_off[i];
-                const bool bad_b = b_off[i] > n_syms || (uint64_t)b_len[i] > n_syms - b_off[i];
-                if (!bad_a && !bad_b) continue;
-                malcs_set_error("sequence [%llu,+%u) outside the symbol buffer of %llu bytes", (unsigned long long)(bad_a ? a_off[i] : b_off[i]),
-                                bad_a ? a_len[i] : b_len[i], (unsigned long long)n_syms);
-                return MALCS_ERR_ARG;
+        if (bad) return report_bad();
+    }
+    if (threaded) {
+        // the same three passes (inside the buffer? apart? places) over stretches of pairs, on the context's threads; a
+        // batch that shares sequences, or has a bad one, goes through the serial code below for its table / its message
+        malcs_workers *wk = malcs_ctx_workers(ctx);
+        const int T = wk->size();
+        struct part { uint64_t blocks = 0, a_min = ~0ull, b_min = ~0ull; uint32_t max_len = 0; bool bad = false, interleaved = true, ordered = true; };
+        std::vector<part> parts((size_t)T);
+        auto range = [&](int k, uint64_t &lo, uint64_t &hi) { lo = n_pairs * (uint64_t)k / (uint64_t)T; hi = n_pairs * (uint64_t)(k + 1) / (uint64_t)T; };
+        wk->run(T, [&](int k) {
+            uint64_t lo, hi; range(k, lo, hi);
+            part pt;
+            uint64_t bad = 0;
+            uint64_t end = lo ? b_off[lo - 1] + b_len[lo - 1] : 0, a_end = lo ? a_off[lo - 1] + a_len[lo - 1] : 0, b_end = end;
+            for (uint64_t i = lo; i < hi; i++) {
+                bad |= (uint64_t)(a_off[i] > n_syms) | (uint64_t)((uint64_t)a_len[i] > n_syms - a_off[i]) |
+                       (uint64_t)(b_off[i] > n_syms) | (uint64_t)((uint64_t)b_len[i] > n_syms - b_off[i]);
+                pt.interleaved = pt.interleaved && a_off[i] >= end && b_off[i] >= a_off[i] + a_len[i];
+                end = b_off[i] + b_len[i];
+                pt.ordered = pt.ordered && a_off[i] >= a_end && b_off[i] >= b_end;
+                a_end = a_off[i] + a_len[i]; b_end = end;
+                pt.a_min = std::min(pt.a_min, a_off[i]); pt.b_min = std::min(pt.b_min, b_off[i]);
+                pt.blocks += (a_len[i] + 31u) / 32u + (b_len[i] + 31u) / 32u;
+                pt.max_len = std::max(pt.max_len, std::max(a_len[i], b_len[i]));
             }
+            pt.bad = bad != 0;
+            parts[(size_t)k] = pt;
+        });
+        bool bad = false, interleaved = true, ordered = true;
+        uint64_t a_min = ~0ull, b_min = ~0ull, blocks = 0;
+        for (const part &pt : parts) {
+            bad = bad || pt.bad; interleaved = interleaved && pt.interleaved; ordered = ordered && pt.ordered;
+            a_min = std::min(a_min, pt.a_min); b_min = std::min(b_min, pt.b_min); blocks += pt.blocks;
+        }
+        if (bad) return report_bad();
+        const uint64_t a_end = a_off[n_pairs - 1] + a_len[n_pairs - 1], b_end = b_off[n_pairs - 1] + b_len[n_pairs - 1];
+        const bool apart = (interleaved || (ordered && (a_end <= b_min || b_end <= a_min)));
+        if (apart && blocks * NP >= 0xffffffffull) { malcs_set_error("batch needs more than 16 GiB of packed planes; split it"); return MALCS_ERR_TOO_LONG; }
+        if (apart) {
+            seq_byte_off.resize((size_t)n_pairs * 2); seq_len.resize((size_t)n_pairs * 2); seq_blk_off.resize((size_t)n_pairs * 2);
+            uint64_t acc = 0;
+            for (part &pt : parts) { const uint64_t mine = pt.blocks; pt.blocks = acc; acc += mine; b->max_len = std::max(b->max_len, pt.max_len); }
+            wk->run(T, [&](int k) {
+                uint64_t lo, hi; range(k, lo, hi);
+                uint64_t at = parts[(size_t)k].blocks;
+                for (uint64_t i = lo; i < hi; i++) {
+                    seq_byte_off[2 * i] = a_off[i]; seq_len[2 * i] = a_len[i]; seq_blk_off[2 * i] = (uint32_t)at;
+                    b->a_off[i] = (uint32_t)at * NP; b->a_len[i] = a_len[i];
+                    at += (a_len[i] + 31u) / 32u;
+                    seq_byte_off[2 * i + 1] = b_off[i]; seq_len[2 * i + 1] = b_len[i]; seq_blk_off[2 * i + 1] = (uint32_t)at;
+                    b->b_off[i] = (uint32_t)at * NP; b->b_len[i] = b_len[i];
+                    at += (b_len[i] + 31u) / 32u;
+                }
+            });
+            total_blocks = acc;
+            placed = true;
         }
     }
-    if (sequences_apart(a_off, a_len, b_off, b_len, n_pairs)) {
+    if (!placed) { seq_byte_off.clear(); seq_len.clear(); seq_blk_off.clear(); }   // (placed: every entry was written; no refill of 3 MB)
+    if (placed) {
+    } else if (sequences_apart(a_off, a_len, b_off, b_len, n_pairs)) {
         seq_byte_off.resize((size_t)n_pairs * 2); seq_len.resize((size_t)n_pairs * 2); seq_blk_off.resize((size_t)n_pairs * 2);
         for (uint64_t i = 0; i < n_pairs; i++) {
             seq_byte_off[2 * i] = a_off[i]; seq_len[2 * i] = a_len[i]; seq_blk_off[2 * i] = (uint32_t)total_blocks;
@@ -443,7 +518,7 @@ static int batch_build(malcs_ctx *ctx, const uint8_t *syms, const uint8_t *d_sym
             const int rc = malcs_host_pack(job, threads, [&](size_t first, size_t count) -> int {
                 copy_error = hipMemcpyAsync(b->d_planes + first, job.out + first, count * sizeof(uint32_t), hipMemcpyHostToDevice, st);
                 return copy_error == hipSuccess ? 0 : 1;
-            }, &codes);
+            }, &codes, threads > 1 && n_pairs >= 16384 ? malcs_ctx_workers(ctx) : nullptr);
             if (rc) { malcs_set_error("copy of the packed planes failed: %s", hipGetErrorString(copy_error)); return MALCS_ERR_HIP; }
             if (codes >> NP) {
                 malcs_set_error("symbol code %u and n_symbols = %d: the batch has codes beyond the %u bit planes n_symbols selects", codes, n_symbols, NP);

@@ -32,6 +32,7 @@
 // the full-matrix kernel spends 4 * ceil(m / 32) + 2 on (130 for 1 kb).
 #include "malcs_internal.hpp"
 #include "malcs_device.hpp"
+#include "malcs_hostpack.hpp"
 #include <algorithm>
 #include <atomic>
 #include <cstdlib>
@@ -1143,9 +1144,9 @@ static int plan_window(malcs_batch *b, int nlw, const std::vector<uint32_t> &pai
         // Deals `todo` to the SIMDs [lo, hi) of a launch of n workgroups (SIMD i holds workgroups i, i + S, ...), most
         // expensive first, each to the least loaded SIMD with a free slot (ties: fewest slots, then lowest number);
         // returns the largest load.  Heap of packed keys: load << 32 | slots << 16 | SIMD.
-        std::vector<uint64_t> heap;
-        std::vector<uint32_t> used;
         auto deal = [&](std::vector<piece> &todo, uint32_t lo, uint32_t hi, uint32_t n, std::vector<piece> &out) -> uint64_t {
+            std::vector<uint64_t> heap;
+            std::vector<uint32_t> used;
             std::stable_sort(todo.begin(), todo.end(), [&](const piece &x, const piece &y) { return cost(x) > cost(y); });
             heap.clear();
             used.assign(S, 0u);
@@ -1220,8 +1221,19 @@ static int plan_window(malcs_batch *b, int nlw, const std::vector<uint32_t> &pai
                 }
             }
             std::vector<piece> alt(n);
-            const uint64_t w0 = deal(minor, minor_a ? 0u : r, minor_a ? r : S, n, alt);
-            const uint64_t w1 = deal(major, minor_a ? r : 0u, minor_a ? S : r, n, alt);
+            uint64_t w0 = 0, w1 = 0, w_plain = ~0ull;
+            const bool side_by_side = count >= 16384;              // the three deals at once, on the context's threads
+            if (side_by_side) {
+                pieces.assign(n, piece{});
+                malcs_ctx_workers(ctx)->run(3, [&](int k) {
+                    if (k == 0) w1 = deal(major, minor_a ? r : 0u, minor_a ? S : r, n, alt);
+                    else if (k == 1) w0 = deal(minor, minor_a ? 0u : r, minor_a ? r : S, n, alt);
+                    else w_plain = deal(todo, 0, S, n, pieces);
+                });
+            } else {
+                w0 = deal(minor, minor_a ? 0u : r, minor_a ? r : S, n, alt);
+                w1 = deal(major, minor_a ? r : 0u, minor_a ? S : r, n, alt);
+            }
             // what the plain plan cannot beat: its fuller SIMDs hold q + 1 pieces, at best the smallest ones
             std::vector<uint32_t> small;
             for (uint32_t t = 0; t < std::min(n_tiles, q + 1u); t++) {
@@ -1231,7 +1243,7 @@ static int plan_window(malcs_batch *b, int nlw, const std::vector<uint32_t> &pai
             std::sort(small.begin(), small.end());
             uint64_t bound = 0;
             for (uint32_t k = 0; k <= q; k++) bound += small[k] * 12u;
-            if (std::max(w0, w1) <= bound || std::max(w0, w1) < deal(todo, 0, S, n, pieces)) pieces.swap(alt);
+            if (std::max(w0, w1) <= bound || std::max(w0, w1) < (side_by_side ? w_plain : deal(todo, 0, S, n, pieces))) pieces.swap(alt);
             dealt = true;
         }
         if (!dealt) deal(todo, 0, S, n, pieces);

@@ -24,6 +24,7 @@
 // Algorithmic work: 4 dword ops per 32 cells for DNA = 0.125 lane-op per cell.
 #include "malcs_internal.hpp"
 #include "malcs_device.hpp"
+#include "malcs_hostpack.hpp"
 #include <algorithm>
 
 namespace {
@@ -405,50 +406,106 @@ int malcs_dist_plan(malcs_batch *b)
     if (const char *e = getenv("MALCS_DIAG_NLW")) nlw = atoi(e);
     const bool window = nlw > 0 && b->n_planes <= 4;
     const uint32_t T = window ? (uint32_t)malcs_diag_threshold(nlw) : 0u;
-    std::vector<uint8_t> cls(n), in_window(n, 0);
+    std::vector<uint8_t> &cls = b->plan_cls, &in_window = b->plan_in_window;
+    cls.resize(n); in_window.resize(n);
     uint64_t cells = 0, n_window = 0;
-    uint32_t last_words = 0xffffffffu; uint8_t last_cls = 0;        // batches of equal lengths: one lookup
-    for (uint64_t i = 0; i < n; i++) {
-        const uint32_t la = b->a_len[i], lb = b->b_len[i];
-        const uint32_t m = std::min(la, lb), mx = std::max(la, lb);
-        cells += (uint64_t)la * lb;
-        const uint32_t words = std::max<uint32_t>(1u, (m + 63u) / 64u);
-        if (words != last_words) {
-            last_words = words;
-            int W, logL = 0;
-            if (words <= 4 && (int)words <= wmax) {
-                W = (int)pow2ceil(words);
-                last_cls = class_of(W, 0);
-            } else {
-                W = 4;
-                while ((uint32_t)W * 64u < words && W < wmax) W *= 2;
-                if ((uint32_t)W * 64u < words) {
-                    last_cls = 255;                    // too long for a resident pattern: sliding-window kernel
-                } else {
-                    const uint32_t lanes = pow2ceil((words + (uint32_t)W - 1u) / (uint32_t)W);
-                    while ((1u << logL) < lanes) logL++;
-                    last_cls = class_of(W, logL);
-                }
-            }
+    // the class of a pair follows from the 64-bit words of its shorter side alone
+    auto class_of_words = [&](uint32_t words) -> uint8_t {
+        int W, logL = 0;
+        if (words <= 4 && (int)words <= wmax) return class_of((int)pow2ceil(words), 0);
+        W = 4;
+        while ((uint32_t)W * 64u < words && W < wmax) W *= 2;
+        if ((uint32_t)W * 64u < words) return 255;                  // too long for a resident pattern: sliding-window kernel
+        const uint32_t lanes = pow2ceil((words + (uint32_t)W - 1u) / (uint32_t)W);
+        while ((1u << logL) < lanes) logL++;
+        return class_of(W, logL);
+    };
+    auto classify = [&](uint64_t lo, uint64_t hi, const uint8_t *by_words, uint64_t &cells_out, uint64_t &window_out, std::vector<uint32_t> &band) {
+        uint64_t cl = 0, nw = 0;
+        uint32_t last_words = 0xffffffffu; uint8_t last_cls = 0;    // batches of equal lengths: one lookup
+        for (uint64_t i = lo; i < hi; i++) {
+            const uint32_t la = b->a_len[i], lb = b->b_len[i];
+            const uint32_t m = std::min(la, lb), mx = std::max(la, lb);
+            cl += (uint64_t)la * lb;
+            const uint32_t words = std::max<uint32_t>(1u, (m + 63u) / 64u);
+            if (words != last_words) { last_words = words; last_cls = by_words ? by_words[words] : class_of_words(words); }
+            cls[i] = last_cls;
+            in_window[i] = 0;
+            if (last_cls == 255) { band.push_back((uint32_t)i); continue; }
+            if (window && (m + 31u) / 32u >= 2u * (uint32_t)nlw + 2u && mx - m <= T) { in_window[i] = 1; nw++; }
         }
-        cls[i] = last_cls;
-        if (last_cls == 255) { b->band_pairs.push_back((uint32_t)i); continue; }
-        if (window && (m + 31u) / 32u >= 2u * (uint32_t)nlw + 2u && mx - m <= T) { in_window[i] = 1; n_window++; }
+        cells_out = cl; window_out = nw;
+    };
+    malcs_workers *wk = n >= 16384 ? malcs_ctx_workers(b->ctx) : nullptr;
+    const int NT = wk ? wk->size() : 1;
+    std::vector<uint64_t> part_window((size_t)NT, 0);
+    auto range = [&](int k, uint64_t &lo, uint64_t &hi) { lo = n * (uint64_t)k / (uint64_t)NT; hi = n * (uint64_t)(k + 1) / (uint64_t)NT; };
+    if (wk) {
+        // large batches, on the context's threads: the classes of all word counts up to the longest sequence first (the
+        // table is shared), then the pairs in stretches
+        const uint32_t max_words = std::max<uint32_t>(1u, (b->max_len + 63u) / 64u);
+        std::vector<uint8_t> seen((size_t)max_words + 1, 0), by_words((size_t)max_words + 1, 0);
+        wk->run(NT, [&](int k) {
+            uint64_t lo, hi; range(k, lo, hi);
+            for (uint64_t i = lo; i < hi; i++)
+                __atomic_store_n(&seen[std::max<uint32_t>(1u, (std::min(b->a_len[i], b->b_len[i]) + 63u) / 64u)], (uint8_t)1, __ATOMIC_RELAXED);
+        });
+        for (uint32_t w = 1; w <= max_words; w++) if (seen[w]) by_words[w] = class_of_words(w);
+        std::vector<uint64_t> part_cells((size_t)NT, 0);
+        std::vector<std::vector<uint32_t>> part_band((size_t)NT);
+        wk->run(NT, [&](int k) {
+            uint64_t lo, hi; range(k, lo, hi);
+            classify(lo, hi, by_words.data(), part_cells[(size_t)k], part_window[(size_t)k], part_band[(size_t)k]);
+        });
+        for (int k = 0; k < NT; k++) {
+            cells += part_cells[(size_t)k]; n_window += part_window[(size_t)k];
+            b->band_pairs.insert(b->band_pairs.end(), part_band[(size_t)k].begin(), part_band[(size_t)k].end());
+        }
+    } else {
+        classify(0, n, nullptr, cells, n_window, b->band_pairs);
+        part_window[0] = n_window;
     }
     b->full_cells = cells;
     malcs_diag_release(b);
     if (n_window >= 64) {
-        std::vector<uint32_t> diag_pairs(n_window);
-        std::vector<uint8_t> diag_cls(n_window);
+        std::vector<uint32_t> &diag_pairs = b->plan_diag_pairs;
+        std::vector<uint8_t> &diag_cls = b->plan_diag_cls;
+        diag_pairs.resize(n_window); diag_cls.resize(n_window);
         std::vector<int> retry_id(table.size(), -1);
         std::vector<diag_retry> classes;
-        size_t k = 0;
-        for (uint64_t i = 0; i < n; i++) {
-            if (!in_window[i]) continue;
-            int &id = retry_id[cls[i]];
-            if (id < 0) { id = (int)classes.size(); diag_retry r; r.W = table[cls[i]].W; r.L = 1 << table[cls[i]].logL; classes.push_back(r); }
-            diag_pairs[k] = (uint32_t)i; diag_cls[k] = (uint8_t)id; k++;
-            cls[i] = 254;                              // not in the direct launches
+        if (wk) {
+            // which classes have pairs in the window class (ids in the order of the table), then the lists in stretches
+            std::vector<uint8_t> used(table.size() * (size_t)NT, 0);
+            wk->run(NT, [&](int k) {
+                uint64_t lo, hi; range(k, lo, hi);
+                uint8_t *u = used.data() + table.size() * (size_t)k;
+                for (uint64_t i = lo; i < hi; i++) if (in_window[i]) u[cls[i]] = 1;
+            });
+            for (size_t c = 0; c < table.size(); c++) {
+                bool any = false;
+                for (int k = 0; k < NT; k++) any = any || used[table.size() * (size_t)k + c];
+                if (any) { retry_id[c] = (int)classes.size(); diag_retry r; r.W = table[c].W; r.L = 1 << table[c].logL; classes.push_back(r); }
+            }
+            std::vector<uint64_t> first((size_t)NT + 1, 0);
+            for (int k = 0; k < NT; k++) first[(size_t)k + 1] = first[(size_t)k] + part_window[(size_t)k];
+            wk->run(NT, [&](int k) {
+                uint64_t lo, hi; range(k, lo, hi);
+                size_t at = first[(size_t)k];
+                for (uint64_t i = lo; i < hi; i++) {
+                    if (!in_window[i]) continue;
+                    diag_pairs[at] = (uint32_t)i; diag_cls[at] = (uint8_t)retry_id[cls[i]]; at++;
+                    cls[i] = 254;                          // not in the direct launches
+                }
+            });
+        } else {
+            size_t k = 0;
+            for (uint64_t i = 0; i < n; i++) {
+                if (!in_window[i]) continue;
+                int &id = retry_id[cls[i]];
+                if (id < 0) { id = (int)classes.size(); diag_retry r; r.W = table[cls[i]].W; r.L = 1 << table[cls[i]].logL; classes.push_back(r); }
+                diag_pairs[k] = (uint32_t)i; diag_cls[k] = (uint8_t)id; k++;
+                cls[i] = 254;                              // not in the direct launches
+            }
         }
         trace.lap("classes");
         int rc = malcs_diag_plan(b, nlw, diag_pairs, diag_cls, classes);

@@ -14,6 +14,8 @@
 #include <algorithm>
 #include <cstring>
 #include <thread>
+#include <mutex>
+#include <condition_variable>
 #include <system_error>
 #include <immintrin.h>
 
@@ -100,7 +102,81 @@ range_fn pick(int np)
 
 }  // namespace
 
-int malcs_host_pack(const malcs_pack_job &job, int max_threads, const std::function<int(size_t, size_t)> &ship, uint32_t *codes_seen)
+struct malcs_workers::impl {
+    std::mutex m;
+    std::condition_variable wake, done;
+    std::vector<std::thread> threads;
+    const std::function<void(int)> *job = nullptr;
+    std::atomic<uint64_t> generation{0};
+    int use = 0;                     // workers 1 ... use - 1 take part in the current stretch
+    std::atomic<int> running{0};
+    bool stop = false;
+
+    void loop(int k)
+    {
+        uint64_t seen = 0;
+        for (;;) {
+            // awake for a moment after a stretch: the next one of the same call comes within microseconds
+            for (int spin = 0; spin < 20000 && generation.load(std::memory_order_acquire) == seen; spin++) _mm_pause();
+            const std::function<void(int)> *fn = nullptr;
+            {
+                std::unique_lock<std::mutex> lock(m);
+                wake.wait(lock, [&] { return stop || generation.load(std::memory_order_relaxed) != seen; });
+                if (stop) return;
+                seen = generation.load(std::memory_order_relaxed);
+                if (k < use) fn = job;
+            }
+            if (!fn) continue;
+            (*fn)(k);
+            if (running.fetch_sub(1, std::memory_order_acq_rel) == 1) {
+                std::lock_guard<std::mutex> lock(m);
+                done.notify_all();
+            }
+        }
+    }
+};
+
+malcs_workers::malcs_workers(int n_threads) : p_(new impl), n_(1)
+{
+    try {
+        for (int k = 1; k < n_threads; k++) { p_->threads.emplace_back([this, k] { p_->loop(k); }); n_ = k + 1; }
+    } catch (const std::system_error &) {}              // no more threads to be had: the ones we have do the work
+}
+
+malcs_workers::~malcs_workers()
+{
+    {
+        std::lock_guard<std::mutex> lock(p_->m);
+        p_->stop = true;
+    }
+    p_->wake.notify_all();
+    for (std::thread &t : p_->threads) t.join();
+    delete p_;
+}
+
+void malcs_workers::begin(int use, const std::function<void(int)> &fn)
+{
+    use = std::max(1, std::min(use, n_));
+    {
+        std::lock_guard<std::mutex> lock(p_->m);
+        p_->job = &fn;
+        p_->use = use;
+        p_->running.store(use - 1, std::memory_order_relaxed);
+        p_->generation.fetch_add(1, std::memory_order_release);
+    }
+    p_->wake.notify_all();
+}
+
+void malcs_workers::end()
+{
+    for (int spin = 0; spin < 20000 && p_->running.load(std::memory_order_acquire) != 0; spin++) _mm_pause();
+    std::unique_lock<std::mutex> lock(p_->m);
+    p_->done.wait(lock, [&] { return p_->running.load(std::memory_order_acquire) == 0; });
+    p_->job = nullptr;
+}
+
+int malcs_host_pack(const malcs_pack_job &job, int max_threads, const std::function<int(size_t, size_t)> &ship, uint32_t *codes_seen,
+                    malcs_workers *workers)
 {
     range_fn fn = pick(job.n_planes);
     if (!fn) return -1;
@@ -132,11 +208,17 @@ int malcs_host_pack(const malcs_pack_job &job, int max_threads, const std::funct
     };
     const size_t want = std::min<size_t>((size_t)std::max(1, max_threads), n_chunks);
     std::vector<std::thread> pool;
-    try {
-        for (size_t t = 1; t < want; t++) pool.emplace_back(work);
-    } catch (const std::system_error &) {}              // no more threads to be had: the ones we have do the rest
+    const std::function<void(int)> work_k = [&](int) { work(); };
+    const bool kept = workers && workers->size() > 1 && want > 1;
+    if (kept) {
+        workers->begin((int)want, work_k);
+    } else {
+        try {
+            for (size_t t = 1; t < want; t++) pool.emplace_back(work);
+        } catch (const std::system_error &) {}          // no more threads to be had: the ones we have do the rest
+    }
     int rc = 0;
-    if (pool.empty()) work();                            // small input, or no threads: pack here, then ship
+    if (!kept && pool.empty()) work();                   // small input, or no threads: pack here, then ship
     // finished chunks leave in order, a few megabytes at a time (a copy has a fixed cost of several microseconds)
     const size_t ship_dwords = (4u << 20) / sizeof(uint32_t);
     size_t pending_first = 0, pending_end = 0;
@@ -159,6 +241,7 @@ int malcs_host_pack(const malcs_pack_job &job, int max_threads, const std::funct
             pending_first = pending_end;
         }
     }
+    if (kept) workers->end();
     for (std::thread &t : pool) t.join();
     uint64_t seen = seen_all.load();
     seen |= seen >> 32; seen |= seen >> 16; seen |= seen >> 8;

@@ -76,7 +76,10 @@ struct malcs_ctx {
     std::vector<uint64_t> seq_byte_off;
     std::vector<uint32_t> seq_len, seq_blk_off;
     std::vector<struct malcs_batch *> spare_batches;
+    // host threads for the parallel stretches of batch creation (malcs_hostpack.hpp), started with the first large batch
+    class malcs_workers *workers = nullptr;
 };
+class malcs_workers *malcs_ctx_workers(malcs_ctx *ctx);   // at most 16 (MALCS_PACK_THREADS), never more than the machine has
 
 // Pinned host memory from a process-wide pool (blocks are kept when they are released: pinning a hundred megabytes
 // costs tens of milliseconds, and results that come home into pageable memory pay for every fresh page).
@@ -180,6 +183,8 @@ struct malcs_batch {
     uint32_t *d_pair_block = nullptr;    // the allocation d_a_off ... d_dist are parts of
     // host mirrors
     std::vector<uint32_t> a_off, a_len, b_off, b_len;   // dword offsets into d_planes / lengths in symbols
+    std::vector<uint8_t> plan_cls, plan_in_window, plan_diag_cls;   // scratch of malcs_dist_plan, kept with the object (pages)
+    std::vector<uint32_t> plan_diag_pairs;
     std::vector<dist_bucket> dist_buckets;
     std::vector<uint32_t> band_pairs;    // pairs too long for a resident pattern: sliding-window kernel
     diag_plan diag;
