@@ -49,6 +49,7 @@ def _load():
         "malcs_edit_distance_fetch": (c.c_int, [vp, vp]),
         "malcs_edit_distance_time": (c.c_int, [vp, c.c_int, P(c.c_float)]),
         "malcs_edit_distance_time_kernel": (c.c_int, [vp, c.c_int, P(c.c_float)]),
+        "malcs_edit_distance_kernel_durations": (c.c_int, [vp, c.c_int, vp]),
         "malcs_batch_plan_info": (c.c_int, [vp, P(c.c_uint64)]),
         "malcs_edit_distance_batch": (c.c_int, [vp, vp, u64, vp, vp, vp, vp, u64, c.c_int, vp]),
         "malcs_edit_distance_noalloc": (c.c_int, [vp, vp, vp, u64, vp, vp, vp, vp, u64, c.c_int, vp]),
@@ -249,6 +250,12 @@ class Batch:
         ms = ctypes.c_float()
         check(lib.malcs_edit_distance_time_kernel(self.handle, int(iters), ctypes.byref(ms)))
         return ms.value
+
+    def kernel_durations(self, iters):
+        """ms of each of `iters` back-to-back launches of the window kernel (one HIP event pair per launch)."""
+        out = np.zeros(int(iters), dtype=np.float32)
+        check(lib.malcs_edit_distance_kernel_durations(self.handle, int(iters), ptr(out)))
+        return out
 
     def plan_info(self):
         info = (ctypes.c_uint64 * 8)()

@@ -33,6 +33,7 @@
 #include "malcs_internal.hpp"
 #include "malcs_device.hpp"
 #include "malcs_hostpack.hpp"
+#include <hip/hip_ext.h>
 #include <algorithm>
 #include <atomic>
 #include <cstdlib>
@@ -1320,7 +1321,7 @@ int malcs_diag_plan(malcs_batch *b, int nlw, const std::vector<uint32_t> &pairs,
 // Launches the window kernel.  The retry counters exist twice: a launch appends through one set and zeroes
 // the other one for its successor (stream order makes that safe), which saves a memset per launch.
 // `advance` = false re-uses the current set without resetting it.
-int malcs_diag_launch(malcs_batch *b, bool advance)
+int malcs_diag_launch(malcs_batch *b, bool advance, hipEvent_t start, hipEvent_t stop)
 {
     diag_plan &d = b->diag;
     if (!d.nlw) return MALCS_OK;
@@ -1340,8 +1341,13 @@ int malcs_diag_launch(malcs_batch *b, bool advance)
     const char *stamp_path = getenv("MALCS_DIAG_STAMPS");          // dev: per-wave time stamps of this launch into a file
     if (getenv("MALCS_DIAG_NORETRY")) stamps = reinterpret_cast<unsigned long long *>(1);
     else if (stamp_path && *stamp_path) { MALCS_HIP(hipMalloc((void **)&stamps, (size_t)d.n_pieces * 48)); MALCS_HIP(hipMemsetAsync(stamps, 0, (size_t)d.n_pieces * 48, st)); }
-    hipLaunchKernelGGL(fn, dim3(d.n_pieces), dim3(64), 0, st, d.d_rows, d.d_piece_off, d.d_piece_info, d.d_piece_join, b->d_dist,
-                       d.d_retry_list, d.d_retry_first, d.d_retry_cap, cur, next, advance ? ncls : 0u, d.d_join_buf, stamps);
+    if (start || stop)     // the dispatch's own time stamps (what a profiler reports as the kernel's duration)
+        hipExtLaunchKernelGGL(fn, dim3(d.n_pieces), dim3(64), 0, st, start, stop, 0, (const uint32_t *)d.d_rows, (const uint32_t *)d.d_piece_off,
+                              (const uint32_t *)d.d_piece_info, (const uint32_t *)d.d_piece_join, b->d_dist, d.d_retry_list,
+                              (const uint32_t *)d.d_retry_first, (const uint32_t *)d.d_retry_cap, cur, next, advance ? ncls : 0u, d.d_join_buf, stamps);
+    else
+        hipLaunchKernelGGL(fn, dim3(d.n_pieces), dim3(64), 0, st, d.d_rows, d.d_piece_off, d.d_piece_info, d.d_piece_join, b->d_dist,
+                           d.d_retry_list, d.d_retry_first, d.d_retry_cap, cur, next, advance ? ncls : 0u, d.d_join_buf, stamps);
     MALCS_HIP(hipGetLastError());
     if (stamps > reinterpret_cast<unsigned long long *>(1)) {
         std::vector<unsigned long long> host((size_t)d.n_pieces * 6);

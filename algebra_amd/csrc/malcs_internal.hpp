@@ -210,7 +210,7 @@ int malcs_pack_launch(malcs_ctx *ctx, const uint8_t *d_syms, const uint64_t *d_s
 // pairs[i] goes to the window class; retry_class[i] indexes `classes` (its full-matrix launch class)
 int malcs_diag_plan(malcs_batch *b, int nlw, const std::vector<uint32_t> &pairs, const std::vector<uint8_t> &retry_class,
                     const std::vector<diag_retry> &classes);
-int malcs_diag_launch(malcs_batch *b, bool advance);
+int malcs_diag_launch(malcs_batch *b, bool advance, hipEvent_t start = nullptr, hipEvent_t stop = nullptr);   // events: the launch's own start and end
 void malcs_diag_release(malcs_batch *b);
 int malcs_diag_threshold(int nlw);
 

@@ -295,7 +295,20 @@ def main():
     launches = max(args.steps, 500)
     step_ms = batch.time_distances(launches) / launches
     batch.time_dominant_kernel(100)
-    kernel_ms = batch.time_dominant_kernel(launches) / launches
+    back_to_back_ms = batch.time_dominant_kernel(launches) / launches     # one event pair around all launches: + the gap between two kernels
+    kernel_timing = {"back_to_back_ms": round(back_to_back_ms, 4)}
+    if plan["window_pairs"]:
+        # the kernel's average launch duration: one HIP event pair per launch (hipExtLaunchKernelGGL's start / stop events,
+        # the dispatch's own time stamps -- what rocprofv3 lists as the kernel's duration), launches back to back
+        each = batch.kernel_durations(launches)
+        kernel_ms = float(each.mean())
+        kernel_timing.update({"how": "mean over one HIP event pair per launch (start/stop events of the dispatch), launches back to back; "
+                                     "back_to_back_ms = one event pair around all launches / their number (adds the gap between two kernels of a stream)",
+                              "median_ms": round(float(np.median(each)), 4), "min_ms": round(float(each.min()), 4),
+                              "p90_ms": round(float(np.percentile(each, 90)), 4)})
+    else:
+        kernel_ms = back_to_back_ms
+        kernel_timing["how"] = "one HIP event pair around all launches / their number"
     if plan["window_pairs"]:
         kernel_cells = float(plan["window_cells"])
         kernel_name = f"k_llcs_diag<{plan['window_limbs']},2,true>"
@@ -410,6 +423,7 @@ def main():
             "roofline": {"bound": "valu", "achieved": round(achieved, 2), "peak": round(PEAK_LANE_OPS / 1e12, 1),
                          "unit": "T int32 lane-op/s", "frac": round(achieved * 1e12 / PEAK_LANE_OPS, 4),
                          "traffic": traffic, "traffic_source": traffic_source, "kernel": kernel_name, "kernel_ms": round(kernel_ms, 4),
+                         "kernel_timing": kernel_timing, "frac_back_to_back": round(kernel_cells * OPS_PER_CELL / (back_to_back_ms * 1e-3) / PEAK_LANE_OPS, 4),
                          "step_ms_hip_events": round(step_ms, 4), "launches_timed": launches, "algorithmic": algorithmic},
             "plan": plan,
             "plan_inclusive": {"pairs_per_s": round(args.pairs / plan_s, 1), "ms": round(plan_s * 1e3, 3),

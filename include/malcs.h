@@ -103,6 +103,11 @@ int malcs_batch_plan_info(const malcs_batch *batch, uint64_t *info8);
 /* As _time, but only the batch's dominant kernel (the window kernel when the batch has a window class,
  * else the full-matrix launches), so that its duration can be set against rocprofv3's. */
 int malcs_edit_distance_time_kernel(malcs_batch *batch, int iters, float *ms_total);
+/* The window kernel of the batch launched `iters` times back to back, every launch between a HIP event pair of its own
+ * (hipExtLaunchKernelGGL's start / stop events: the dispatch's time stamps, i.e. what rocprofv3 lists as the kernel's
+ * duration; the gap between two kernels of a stream is in _time_kernel's total and not in these).  ms_each[iters].
+ * Measurement only, like the two above: no counterpart in the reference.  Error when the batch has no window class. */
+int malcs_edit_distance_kernel_durations(malcs_batch *batch, int iters, float *ms_each);
 
 /* One-shot convenience: create + launch + fetch + destroy. */
 int malcs_edit_distance_batch(malcs_ctx *ctx, const uint8_t *syms, uint64_t n_syms,

@@ -201,10 +201,19 @@ def test_edit_distance_window_class(native, nlw, nsym, monkeypatch):
     assert info["window_limbs"] == (nlw if nlw else 0)
     got = batch.distances()
     again = batch.distances()                      # second launch: the retry counters start over
+    if nlw:                                        # the measurement entry (an event pair per launch) leaves the results alone
+        each = batch.kernel_durations(3)
+        assert each.shape == (3,) and (each > 0).all() and (each < 50).all()
+        third = batch.distances()
+    else:
+        with pytest.raises(native.MalcsError):
+            batch.kernel_durations(3)
+        third = again
     batch.close()
     ref = O.edit_distance_batch(*data)
     assert np.array_equal(got, ref)
     assert np.array_equal(again, ref)
+    assert np.array_equal(third, ref)
     if nlw:
         assert (ref > 32 * nlw - 32).sum() > 50 and (ref <= 32 * nlw - 32).sum() > 50
 
