@@ -92,3 +92,17 @@ def test_sanitizer_run_of_host_graph_code():
     done = subprocess.run(["make", "-C", os.path.join(root, "oracle"), "asan", "ASAN_CASES=400"], capture_output=True, text=True, timeout=600)
     assert done.returncode == 0, done.stdout[-2000:] + done.stderr[-2000:]
     assert "0 mismatches" in done.stdout
+
+
+def test_thread_sanitizer_run_of_host_threads():
+    """`make -C oracle tsan`: the library's kept host threads (malcs_workers) and the packing of symbols into bit planes on
+    them under ThreadSanitizer, kept / own / one thread compared word by word (tests/checks/tsan_pack.cpp)."""
+    import os
+    import shutil
+    import subprocess
+    if not shutil.which("g++") or not shutil.which("make"):
+        pytest.skip("no g++ / make")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    done = subprocess.run(["make", "-C", os.path.join(root, "oracle"), "tsan"], capture_output=True, text=True, timeout=600)
+    assert done.returncode == 0, done.stdout[-2000:] + done.stderr[-2000:]
+    assert "no findings" in done.stdout
