@@ -471,10 +471,15 @@ void canonical_of(pair_graph &G)
 
 struct launch_class { int W, logL; bool band; std::vector<uint32_t> pairs; };
 
-template <typename T> struct dev_buf {
+template <typename T> struct dev_buf {               // device memory of a call, from the context's pool
+    malcs_ctx *c;
     T *p = nullptr;
-    ~dev_buf() { if (p) hipFree(p); }
-    int alloc(size_t n) { if (p) { hipFree(p); p = nullptr; } hipError_t e = hipMalloc(&p, (n ? n : 1) * sizeof(T)); return e == hipSuccess ? 0 : -1; }
+    explicit dev_buf(malcs_ctx *ctx) : c(ctx) {}
+    dev_buf(const dev_buf &) = delete;
+    dev_buf &operator=(const dev_buf &) = delete;
+    ~dev_buf() { release(); }
+    void release() { if (p) { malcs_pool_free(c, p); p = nullptr; } }
+    int alloc(size_t n) { release(); return malcs_pool_alloc(c, (void **)&p, (n ? n : 1) * sizeof(T)) == hipSuccess ? 0 : -1; }
 };
 
 uint32_t pow2ceil(uint32_t x) { uint32_t p = 1; while (p < x) p <<= 1; return p; }
@@ -754,11 +759,11 @@ static int graph_batch(malcs_batch *b, const int64_t *shift, const int64_t *max_
         for (size_t s = 0; s < S.pairs.size(); s++) sweep_slot[S.pairs[s]] = s;
     }
     stages.lap("sweeps");
-    dev_buf<uint32_t> d_work, d_evcap, d_evcnt, d_scratch;
-    dev_buf<uint64_t> d_scoff, d_evoff, d_outoff;
-    dev_buf<int32_t> d_kmin, d_kmax, d_rw, d_llcs, d_fdist;
-    dev_buf<uint8_t> d_skip;
-    dev_buf<event> d_events, d_packed;
+    dev_buf<uint32_t> d_work(b->ctx), d_evcap(b->ctx), d_evcnt(b->ctx), d_scratch(b->ctx);
+    dev_buf<uint64_t> d_scoff(b->ctx), d_evoff(b->ctx), d_outoff(b->ctx);
+    dev_buf<int32_t> d_kmin(b->ctx), d_kmax(b->ctx), d_rw(b->ctx), d_llcs(b->ctx), d_fdist(b->ctx);
+    dev_buf<uint8_t> d_skip(b->ctx);
+    dev_buf<event> d_events(b->ctx), d_packed(b->ctx);
 
     for (const launch_class &lc : classes) {
         const uint64_t NL = 2ull * lc.W;

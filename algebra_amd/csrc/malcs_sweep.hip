@@ -437,10 +437,17 @@ k_sweep_runs(const uint32_t *__restrict__ planes, const uint32_t *__restrict__ a
     if (threadIdx.x == 0) out_cnt[w] = lds_cnt;
 }
 
+// device memory of a call, from the context's pool (a hipMalloc costs a fraction of a millisecond and a hipFree waits for
+// the device; a sweep over a C2 batch used to make fourteen of each)
 template <typename T> struct dbuf {
+    malcs_ctx *c;
     T *p = nullptr;
-    ~dbuf() { if (p) hipFree(p); }
-    int alloc(size_t n) { return hipMalloc(&p, (n ? n : 1) * sizeof(T)) == hipSuccess ? 0 : -1; }   // once per buffer
+    explicit dbuf(malcs_ctx *ctx) : c(ctx) {}
+    dbuf(const dbuf &) = delete;
+    dbuf &operator=(const dbuf &) = delete;
+    ~dbuf() { release(); }
+    void release() { if (p) { malcs_pool_free(c, p); p = nullptr; } }
+    int alloc(size_t n) { release(); return malcs_pool_alloc(c, (void **)&p, (n ? n : 1) * sizeof(T)) == hipSuccess ? 0 : -1; }
 };
 
 template <int NP>
@@ -499,10 +506,10 @@ int malcs_sweep_runs(malcs_batch *b, const std::vector<uint32_t> &work, const in
             end++;
         }
         const uint32_t cnt = (uint32_t)(end - pos);
-        dbuf<uint32_t> d_work, d_counts;
-        dbuf<int32_t> d_fr, d_reached;
-        dbuf<uint64_t> d_fr_off, d_out_off;
-        dbuf<uint4> d_out;
+        dbuf<uint32_t> d_work(b->ctx), d_counts(b->ctx);
+        dbuf<int32_t> d_fr(b->ctx), d_reached(b->ctx);
+        dbuf<uint64_t> d_fr_off(b->ctx), d_out_off(b->ctx);
+        dbuf<uint4> d_out(b->ctx);
         if (d_work.alloc(cnt) || d_counts.alloc(cnt) || d_fr.alloc(fr_total) || d_reached.alloc(cnt) || d_fr_off.alloc(cnt) ||
             d_out_off.alloc(cnt)) {
             malcs_set_error("device allocation failed (sweep chunk of %u pairs)", cnt);
@@ -619,9 +626,9 @@ int malcs_sweep_distances(malcs_batch *b, const std::vector<uint32_t> &pairs, in
     }
     std::vector<uint64_t> fr_off;
     const uint64_t fr_total = fr_layout(ndiag, BIG_DIAGS, fr_off);
-    dbuf<uint32_t> d_work;
-    dbuf<int32_t> d_caps, d_fr, d_dist;
-    dbuf<uint64_t> d_fr_off;
+    dbuf<uint32_t> d_work(b->ctx);
+    dbuf<int32_t> d_caps(b->ctx), d_fr(b->ctx), d_dist(b->ctx);
+    dbuf<uint64_t> d_fr_off(b->ctx);
     if (d_work.alloc(cnt) || d_caps.alloc(cnt) || d_fr.alloc(fr_total) || d_dist.alloc(cnt) || d_fr_off.alloc(cnt)) {
         malcs_set_error("device allocation failed (sweep over %u pairs)", cnt);
         return MALCS_ERR_NOMEM;
@@ -678,10 +685,10 @@ int malcs_sweep_optimal_runs(malcs_batch *b, bool small, const std::vector<uint3
         const uint32_t cnt = (uint32_t)(end - pos);
         std::vector<uint64_t> fr_off_b, fr_off_f;
         const uint64_t fr_b = fr_layout(nd_back, lds_diags, fr_off_b), fr_f = fr_layout(nd_fwd, lds_diags, fr_off_f);
-        dbuf<uint32_t> d_work, d_cap, d_cnt;
-        dbuf<int32_t> d_dists, d_fr, d_tab, d_found;
-        dbuf<uint64_t> d_fr_off, d_tab_off, d_out_off;
-        dbuf<uint4> d_out;
+        dbuf<uint32_t> d_work(b->ctx), d_cap(b->ctx), d_cnt(b->ctx);
+        dbuf<int32_t> d_dists(b->ctx), d_fr(b->ctx), d_tab(b->ctx), d_found(b->ctx);
+        dbuf<uint64_t> d_fr_off(b->ctx), d_tab_off(b->ctx), d_out_off(b->ctx);
+        dbuf<uint4> d_out(b->ctx);
         if (d_work.alloc(cnt) || d_cap.alloc(cnt) || d_cnt.alloc(cnt) || d_dists.alloc(cnt) || d_fr.alloc(std::max(fr_b, fr_f)) ||
             d_tab.alloc(tab_total) || d_found.alloc(cnt) || d_fr_off.alloc(cnt) || d_tab_off.alloc(cnt) || d_out_off.alloc(cnt)) {
             malcs_set_error("device allocation failed (sweep chunk of %u pairs, %llu MiB of reach table)", cnt, (unsigned long long)(tab_total >> 18));
@@ -741,7 +748,7 @@ int malcs_sweep_optimal_runs(malcs_batch *b, bool small, const std::vector<uint3
         }
         MALCS_HIP(malcs_h2d(st, d_fr_off.p, fr_off_f.data(), cntf * 8ull));
         for (int attempt = 0;; attempt++) {
-            if (d_out.p) { hipFree(d_out.p); d_out.p = nullptr; }
+            d_out.release();
             if (d_out.alloc(total)) { malcs_set_error("device allocation failed (%llu runs)", (unsigned long long)total); return MALCS_ERR_NOMEM; }
             MALCS_HIP(malcs_h2d(st, d_cap.p, cap.data(), cntf * 4ull));
             MALCS_HIP(malcs_h2d(st, d_out_off.p, off.data(), cntf * 8ull));
@@ -775,8 +782,8 @@ int malcs_sweep_optimal_runs(malcs_batch *b, bool small, const std::vector<uint3
         out_runs.resize(base + kept * 4);
         stages.lap("host vector for the runs");
         if (kept) {
-            dbuf<uint4> d_packed;
-            dbuf<uint64_t> d_packed_off;
+            dbuf<uint4> d_packed(b->ctx);
+            dbuf<uint64_t> d_packed_off(b->ctx);
             if (d_packed.alloc(kept) || d_packed_off.alloc(cntf)) { malcs_set_error("device allocation failed (%llu runs)", (unsigned long long)kept); return MALCS_ERR_NOMEM; }
             MALCS_HIP(malcs_h2d(st, d_packed_off.p, packed_off.data(), cntf * 8ull));
             rc = malcs_graph_launch_compact(ctx, d_out.p, d_out_off.p, d_cnt.p, d_packed_off.p, cntf, d_packed.p);
