@@ -10,6 +10,7 @@
 //     trimming of source and sink :447-451, supremal :453.
 // The graph builder works on integer node ids and flat arrays; nothing here touches symbols.
 #include "malcs_internal.hpp"
+#include "malcs_hostpack.hpp"
 #include "malcs_graph_core.hpp"
 #include <algorithm>
 #include <atomic>
@@ -952,13 +953,14 @@ static int graph_batch(malcs_batch *b, const int64_t *shift, const int64_t *max_
         if (N < 64 && load < 4096) nt = 1;
         nt = (unsigned)std::min<uint64_t>(nt, std::max<uint64_t>(N, 1));
     }
-    std::vector<std::thread> pool;
+    // on the context's kept threads (started one after the other per call, the sixteenth used to begin 0.4 ms after the first)
+    malcs_workers *wk = nt > 1 ? malcs_ctx_workers(b->ctx) : nullptr;
+    if (wk) nt = std::min<unsigned>(nt, (unsigned)wk->size());
     out->stores.resize(nt);
     out->narrow.resize(nt);
     jobs.builders.store((int)nt);
-    for (unsigned t = 1; t < nt; t++) pool.emplace_back(worker, &out->stores[t], &out->narrow[t]);
-    worker(&out->stores[0], &out->narrow[0]);
-    for (std::thread &t : pool) t.join();
+    if (wk && nt > 1) wk->run((int)nt, [&](int k) { worker(&out->stores[(size_t)k], &out->narrow[(size_t)k]); });
+    else worker(&out->stores[0], &out->narrow[0]);
     out->timing[2] = (float)(now_ms() - t0);
     stages.lap("host build");
     if (trace) fprintf(stderr, "malcs host build: %llu pairs, %u threads, wall %.2f ms; summed over threads: events->runs %.2f ms, build_graph %.2f ms\n",
