@@ -422,6 +422,7 @@ int malcs_dist_plan(malcs_batch *b)
     };
     auto classify = [&](uint64_t lo, uint64_t hi, const uint8_t *by_words, uint64_t &cells_out, uint64_t &window_out, std::vector<uint32_t> &band) {
         uint64_t cl = 0, nw = 0;
+        uint32_t longest = 0;                                       // of the window class (sizes its plan's histogram)
         uint32_t last_words = 0xffffffffu; uint8_t last_cls = 0;    // batches of equal lengths: one lookup
         for (uint64_t i = lo; i < hi; i++) {
             const uint32_t la = b->a_len[i], lb = b->b_len[i];
@@ -432,10 +433,13 @@ int malcs_dist_plan(malcs_batch *b)
             cls[i] = last_cls;
             in_window[i] = 0;
             if (last_cls == 255) { band.push_back((uint32_t)i); continue; }
-            if (window && (m + 31u) / 32u >= 2u * (uint32_t)nlw + 2u && mx - m <= T) { in_window[i] = 1; nw++; }
+            if (window && (m + 31u) / 32u >= 2u * (uint32_t)nlw + 2u && mx - m <= T) { in_window[i] = 1; nw++; longest = std::max(longest, mx); }
         }
         cells_out = cl; window_out = nw;
+        uint32_t seen = __atomic_load_n(&b->plan_window_longest, __ATOMIC_RELAXED);
+        while (longest > seen && !__atomic_compare_exchange_n(&b->plan_window_longest, &seen, longest, false, __ATOMIC_RELAXED, __ATOMIC_RELAXED)) {}
     };
+    b->plan_window_longest = 0;
     malcs_workers *wk = n >= 16384 ? malcs_ctx_workers(b->ctx) : nullptr;
     const int NT = wk ? wk->size() : 1;
     std::vector<uint64_t> part_window((size_t)NT, 0);

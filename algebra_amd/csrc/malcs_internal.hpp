@@ -185,6 +185,7 @@ struct malcs_batch {
     std::vector<uint32_t> a_off, a_len, b_off, b_len;   // dword offsets into d_planes / lengths in symbols
     std::vector<uint8_t> plan_cls, plan_in_window, plan_diag_cls;   // scratch of malcs_dist_plan, kept with the object (pages)
     std::vector<uint32_t> plan_diag_pairs;
+    uint32_t plan_window_longest = 0;                               // longest sequence among the pairs of the window class
     std::vector<dist_bucket> dist_buckets;
     std::vector<uint32_t> band_pairs;    // pairs too long for a resident pattern: sliding-window kernel
     diag_plan diag;
