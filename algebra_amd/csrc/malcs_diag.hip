@@ -59,6 +59,11 @@ constexpr int MALCS_DIAG_HALF_T = 48; // two limbs moving 16 rows per 16 columns
 //
 // items: nine arrays of `count` dwords, one entry per pair of the class (in the order of `pairs`)
 enum { IT_PO, IT_TO, IT_M, IT_N, IT_Q, IT_MT, IT_NT, IT_DELTA, IT_ITERS, ITEM_FIELDS };
+// One record of 16 dwords per pair (half a 128-byte line): the layout kernel reads the records through the sort's
+// permutation, and with a table per field every field of every pair was a line of its own (230 MB of the 436 MB that
+// kernel fetched per C2 batch, FETCH_SIZE).
+constexpr uint32_t ITEM_STRIDE = 16;
+#define ITEM_AT(field, i) item[(size_t)(i) * ITEM_STRIDE + (field)]
 
 // One lane per pair: common prefix / suffix from the planes (XOR of whole words, first / last differing bit), what is left
 // of the pair after the cut, and the histogram of block counts the tiles are formed from (two groups: length
@@ -120,9 +125,9 @@ k_plan_ends(const uint32_t *__restrict__ planes, const uint32_t *__restrict__ a_
     const uint32_t ragged = (32u - (n & 31u)) & 31u;
     m += ragged; n += ragged;
     const uint32_t iters = n >> 5;
-    item[IT_PO * count + i] = po; item[IT_TO * count + i] = to; item[IT_M * count + i] = m; item[IT_N * count + i] = n;
-    item[IT_Q * count + i] = q; item[IT_MT * count + i] = mt; item[IT_NT * count + i] = nt;
-    item[IT_DELTA * count + i] = delta; item[IT_ITERS * count + i] = iters;
+    ITEM_AT(IT_PO, i) = po; ITEM_AT(IT_TO, i) = to; ITEM_AT(IT_M, i) = m; ITEM_AT(IT_N, i) = n;
+    ITEM_AT(IT_Q, i) = q; ITEM_AT(IT_MT, i) = mt; ITEM_AT(IT_NT, i) = nt;
+    ITEM_AT(IT_DELTA, i) = delta; ITEM_AT(IT_ITERS, i) = iters;
     atomicAdd(&lds_hist[(delta > (uint32_t)MALCS_DIAG_HALF_T ? hist_stride : 0u) + iters], 1u);
     }
     __syncthreads();
@@ -144,7 +149,7 @@ k_plan_scatter(const uint32_t *__restrict__ item, uint32_t count, uint32_t hist_
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     uint32_t key = 0, rank = 0;
     if (i < count) {
-        key = (item[IT_DELTA * count + i] > (uint32_t)MALCS_DIAG_HALF_T ? hist_stride : 0u) + item[IT_ITERS * count + i];
+        key = (ITEM_AT(IT_DELTA, i) > (uint32_t)MALCS_DIAG_HALF_T ? hist_stride : 0u) + ITEM_AT(IT_ITERS, i);
         rank = atomicAdd(&lds_cnt[key], 1u);
     }
     __syncthreads();
@@ -181,7 +186,7 @@ k_diag_layout(const uint32_t *__restrict__ planes, const uint32_t *__restrict__ 
     if (idx == 0xffffffffu) {                                  // an empty slot of the last tile
         if (wave == 0) { out[0] = 0xffffffffu; out[64] = 0u; out[128] = 0u; out[192] = 0u; }
         out += META_ROWS * 64;
-        for (uint32_t r = wave; r < n_rows; r += 4) {
+        for (uint32_t r = wave; r < n_rows; r += blockDim.x >> 6) {
             const uint32_t k = r < (uint32_t)(nlw - 1) ? NP : 2 * NP;
             uint32_t *o = out + (r < (uint32_t)(nlw - 1) ? (size_t)r * NP : (size_t)(nlw - 1) * NP + (size_t)(r - (nlw - 1)) * 2u * NP) * 64u;
             for (uint32_t j = 0; j < k; j++) o[j * 64u] = 0u;
@@ -195,11 +200,11 @@ k_diag_layout(const uint32_t *__restrict__ planes, const uint32_t *__restrict__ 
     // common suffix, which does not change the distance.
     const uint32_t it_tile = tile_iters[tile] & 0x7fffffffu;
     const bool half = tile_iters[tile] >> 31;
-    const uint32_t grow = 32u * (it_tile - item[IT_ITERS * count + idx]);
-    const uint32_t m = item[IT_M * count + idx] + grow, n = item[IT_N * count + idx] + grow;
-    const uint32_t po = item[IT_PO * count + idx], to = item[IT_TO * count + idx], q = item[IT_Q * count + idx];
-    const int mt = (int)item[IT_MT * count + idx], nt = (int)item[IT_NT * count + idx];
-    const int delta = (int)item[IT_DELTA * count + idx];
+    const uint32_t grow = 32u * (it_tile - ITEM_AT(IT_ITERS, idx));
+    const uint32_t m = ITEM_AT(IT_M, idx) + grow, n = ITEM_AT(IT_N, idx) + grow;
+    const uint32_t po = ITEM_AT(IT_PO, idx), to = ITEM_AT(IT_TO, idx), q = ITEM_AT(IT_Q, idx);
+    const int mt = (int)ITEM_AT(IT_MT, idx), nt = (int)ITEM_AT(IT_NT, idx);
+    const int delta = (int)ITEM_AT(IT_DELTA, idx);
     const int Tm = half ? MALCS_DIAG_HALF_T : T;
     const int kmax = delta + (Tm - delta) / 2;
     if (wave == 0) { out[0] = pairs[idx]; out[64] = m; out[128] = n; out[192] = (uint32_t)kmax | ((uint32_t)retry_class[idx] << 16); }
@@ -224,37 +229,64 @@ k_diag_layout(const uint32_t *__restrict__ planes, const uint32_t *__restrict__ 
         }
         return w;
     };
-    // Each wave writes a contiguous quarter of the piece's rows and walks its sequences word by word: a row needs the
-    // 32 symbols from some position `at` of the stored pattern (rows) / text (columns), i.e. words at >> 5 and the next
-    // one, and the next row needs the next words (the previous ones when the piece runs backwards).
+    // Each wave writes a contiguous quarter of the piece's rows: a row needs the 32 symbols from some position `at` of the
+    // stored pattern (rows) / text (columns), i.e. words at >> 5 and the next one, and the next row needs the next words
+    // (the previous ones when the piece runs backwards).
     //   forward:  pattern rows from 32 j - kmax for row j of the piece (j counts the start limbs too), text block it
     //   backward: pattern rows from m - 32 - (32 j - kmax), bit-reversed; text block n / 32 - 1 - it, bit-reversed
-    const uint32_t per = (n_rows + 3u) / 4u, r0 = wave * per, r1 = min(n_rows, r0 + per);
+    // Eight rows at a time, all nine words a stream needs for them asked for together instead of a dependent pair of
+    // loads per row.  (The kernel fetches 390 MB per C2 batch for 50 MB of planes, FETCH_SIZE, 69 us: a lane reads 8 bytes
+    // of a 128-byte line at a time and almost every such read goes to memory; asking together did not change that, one
+    // record per pair instead of a table per field took 35 MB off.  Open: loads that are coalesced across the lanes.)
+    const uint32_t n_waves = blockDim.x >> 6;
+    const uint32_t per = (n_rows + n_waves - 1u) / n_waves, r0 = wave * per, r1 = min(n_rows, r0 + per);
     if (r0 >= r1) return;
-    const int step = back ? -1 : 1;
     // pattern: position of row j's first symbol in the stored sequence
     auto pat_at = [&](int j) -> int { return (back ? (int)m - 32 - (32 * j - kmax) : 32 * j - kmax) + (int)q; };
-    int pw = pat_at((int)r0) >> 5;                                   // arithmetic shift = floor
     const uint32_t psh = (uint32_t)pat_at((int)r0) & 31u;             // the same for every row: rows are 32 apart
-    word plo = stored(po, mt, pw), phi = stored(po, mt, pw + 1);
-    // text: block `it` of the piece = stored words tb, tb + 1 shifted by q
-    const int first_it = (int)r0 - (nlw - 1);                        // may be negative: the start limbs have no text
-    auto txt_blk = [&](int it) -> int { return back ? (int)(n >> 5) - 1 - it : it; };
-    int tw = txt_blk(first_it < 0 ? 0 : first_it);
-    word tlo = stored(to, nt, tw), thi = stored(to, nt, tw + 1);
-    for (uint32_t r = r0; r < r1; r++) {
-        uint32_t limb[NP];
+    auto limb_of = [&](const word &lo, const word &hi, uint32_t (&limb)[NP]) {
 #pragma unroll
         for (int p = 0; p < NP; p++) {
-            const uint32_t v = psh ? ((plo.p[p] >> psh) | (phi.p[p] << (32u - psh))) : plo.p[p];
+            const uint32_t v = psh ? ((lo.p[p] >> psh) | (hi.p[p] << (32u - psh))) : lo.p[p];
             limb[p] = back ? __brev(v) : v;
         }
-        if (r < (uint32_t)(nlw - 1)) {
+    };
+    // the limbs the window starts with: no text
+    const uint32_t start_rows = (uint32_t)(nlw - 1);
+    for (uint32_t r = r0; r < min(r1, start_rows); r++) {
+        const int pw = pat_at((int)r) >> 5;                          // arithmetic shift = floor
+        uint32_t limb[NP];
+        limb_of(stored(po, mt, pw), stored(po, mt, pw + 1), limb);
 #pragma unroll
-            for (int p = 0; p < NP; p++) out[(r * NP + p) * 64u] = limb[p];
-        } else {
-            const int it = (int)r - (nlw - 1);
-            uint32_t *o = out + (size_t)(nlw - 1) * NP * 64u + (size_t)it * 2u * NP * 64u;
+        for (int p = 0; p < NP; p++) out[(r * NP + p) * 64u] = limb[p];
+    }
+    // text: block `it` of the piece = stored words tb, tb + 1 shifted by q
+    auto txt_blk = [&](int it) -> int { return back ? (int)(n >> 5) - 1 - it : it; };
+    for (uint32_t rc = max(r0, start_rows); rc < r1; rc += 8u) {
+        const int nr = (int)min(8u, r1 - rc);                         // rows of this stretch (the same for every lane)
+        // row j of the stretch: pattern words pw + j, pw + j + 1 forwards (kept at 0 ... 8), pw - j, pw - j + 1 backwards
+        // (kept at 7 - j, 8 - j: the stretch's words start at pw - 7); the text likewise
+        const int pw = pat_at((int)rc) >> 5, tw = txt_blk((int)(rc - start_rows));
+        const int plow = back ? pw - 7 : pw, tlow = back ? tw - 7 : tw;
+        word pc[9], tc[9];
+#pragma unroll
+        for (int k = 0; k < 9; k++) {
+            const bool wanted = back ? k >= 8 - nr : k <= nr;
+            if (wanted) { pc[k] = stored(po, mt, plow + k); tc[k] = stored(to, nt, tlow + k); }
+            else {
+#pragma unroll
+                for (int p = 0; p < NP; p++) { pc[k].p[p] = 0u; tc[k].p[p] = 0u; }
+            }
+        }
+#pragma unroll
+        for (int j = 0; j < 8; j++) {
+            if (j >= nr) break;
+            const word &plo = back ? pc[7 - j] : pc[j], &phi = back ? pc[8 - j] : pc[j + 1];
+            const word &tlo = back ? tc[7 - j] : tc[j], &thi = back ? tc[8 - j] : tc[j + 1];
+            uint32_t limb[NP];
+            limb_of(plo, phi, limb);
+            const uint32_t it = rc + (uint32_t)j - start_rows;
+            uint32_t *o = out + (size_t)start_rows * NP * 64u + (size_t)it * 2u * NP * 64u;
             uint32_t txt[NP];
 #pragma unroll
             for (int p = 0; p < NP; p++) {
@@ -277,12 +309,7 @@ k_diag_layout(const uint32_t *__restrict__ planes, const uint32_t *__restrict__ 
             }
 #pragma unroll
             for (int p = 0; p < NP; p++) o[(NP + p) * 64u] = txt[p];
-            // the text moves on with the blocks only
-            tw += step;
-            if (back) { thi = tlo; tlo = stored(to, nt, tw); } else { tlo = thi; thi = stored(to, nt, tw + 1); }
         }
-        pw += step;
-        if (back) { phi = plo; plo = stored(po, mt, pw); } else { plo = phi; phi = stored(po, mt, pw + 1); }
     }
 }
 
@@ -1026,7 +1053,7 @@ static int plan_window(malcs_batch *b, int nlw, const std::vector<uint32_t> &pai
     }
     size_t temp_dw = 0;
     auto carve = [](size_t &total, size_t dwords) { const size_t at = total; total += (dwords + 63) & ~(size_t)63; return at; };
-    const size_t at_pairs = carve(temp_dw, count), at_cls = carve(temp_dw, (count + 3) / 4), at_item = carve(temp_dw, (size_t)ITEM_FIELDS * count);
+    const size_t at_pairs = carve(temp_dw, count), at_cls = carve(temp_dw, (count + 3) / 4), at_item = carve(temp_dw, (size_t)ITEM_STRIDE * count);
     const size_t at_hist = carve(temp_dw, 2 * (size_t)HB), at_slot = carve(temp_dw, (size_t)((count + 63) / 64) * 64);
     const size_t at_sample = carve(temp_dw, 2 * sample.size() + 1), at_scount = carve(temp_dw, 64);
     pool_scoped<uint32_t> temp(ctx);
@@ -1295,10 +1322,11 @@ static int plan_window(malcs_batch *b, int nlw, const std::vector<uint32_t> &pai
     MALCS_HIP(hipMemsetAsync(d.d_join_buf, 0, (size_t)std::max(n_joins, 1u) * 128u * sizeof(uint32_t), st));
     MALCS_HIP(hipMemsetAsync(d_slot, 0xff, (size_t)n_tiles * 64u * sizeof(uint32_t), st));
     hipLaunchKernelGGL(k_plan_scatter, dim3((count + 1023u) / 1024u), dim3(1024), 2 * hist_lds, st, d_item, count, HB, d_hist, d_slot);
+    const dim3 layout_block(256);      // four waves per piece; with two or one the kernel fetches twice as much and takes 112 / 128 us
     switch (NP) {
-    case 2: hipLaunchKernelGGL(k_diag_layout<2>, dim3(n_pieces), b256, 0, st, b->d_planes, d_item, count, d_pairs, d_cls, d_slot, d_tile_iters, d.d_piece_off, d.d_piece_info, d_piece_tile, nlw, T, d.d_rows); break;
-    case 3: hipLaunchKernelGGL(k_diag_layout<3>, dim3(n_pieces), b256, 0, st, b->d_planes, d_item, count, d_pairs, d_cls, d_slot, d_tile_iters, d.d_piece_off, d.d_piece_info, d_piece_tile, nlw, T, d.d_rows); break;
-    case 4: hipLaunchKernelGGL(k_diag_layout<4>, dim3(n_pieces), b256, 0, st, b->d_planes, d_item, count, d_pairs, d_cls, d_slot, d_tile_iters, d.d_piece_off, d.d_piece_info, d_piece_tile, nlw, T, d.d_rows); break;
+    case 2: hipLaunchKernelGGL(k_diag_layout<2>, dim3(n_pieces), layout_block, 0, st, b->d_planes, d_item, count, d_pairs, d_cls, d_slot, d_tile_iters, d.d_piece_off, d.d_piece_info, d_piece_tile, nlw, T, d.d_rows); break;
+    case 3: hipLaunchKernelGGL(k_diag_layout<3>, dim3(n_pieces), layout_block, 0, st, b->d_planes, d_item, count, d_pairs, d_cls, d_slot, d_tile_iters, d.d_piece_off, d.d_piece_info, d_piece_tile, nlw, T, d.d_rows); break;
+    case 4: hipLaunchKernelGGL(k_diag_layout<4>, dim3(n_pieces), layout_block, 0, st, b->d_planes, d_item, count, d_pairs, d_cls, d_slot, d_tile_iters, d.d_piece_off, d.d_piece_info, d_piece_tile, nlw, T, d.d_rows); break;
     }
     MALCS_HIP(hipGetLastError());
     // copies of more than a megabyte do not go through the staging buffer: their sources (locals) must outlive them
