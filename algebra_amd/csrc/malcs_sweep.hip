@@ -666,6 +666,10 @@ int malcs_sweep_optimal_runs(malcs_batch *b, bool small, const std::vector<uint3
         std::vector<uint64_t> tab_off;
         std::vector<int32_t> dists;
         std::vector<int64_t> nd_back, nd_fwd;
+        {
+            const size_t guess = std::min<size_t>(work.size() - pos, (size_t)1 << 20);
+            tab_off.reserve(guess); dists.reserve(guess); nd_back.reserve(guess); nd_fwd.reserve(guess);
+        }
         uint64_t tab_total = 0;
         size_t end = pos;
         while (end < work.size()) {
@@ -717,28 +721,40 @@ int malcs_sweep_optimal_runs(malcs_batch *b, bool small, const std::vector<uint3
         const uint32_t all = cnt;
         std::vector<uint32_t> keep, fwd_work;
         std::vector<uint64_t> fwd_tab_off;
-        nd_fwd.clear();
-        for (uint32_t s = 0; s < all; s++) {
-            const uint32_t pid = work[pos + s];
-            if (unknown_cap) {
+        std::vector<int32_t> fwd_dists;
+        uint32_t cntf;
+        if (!unknown_cap) {
+            // the distances were known: every pair goes on, and its number, distance, table offset and the forward
+            // pass's layout (worked out above) are what the device already holds or the host already has
+            for (uint32_t s = 0; s < all; s++)
+                if (found[s] != dists[s]) {
+                    malcs_set_error("pair %u: the backward sweep found distance %d, expected %d (internal error)", work[pos + s], found[s], dists[s]);
+                    return MALCS_ERR_INTERNAL;
+                }
+            cntf = all;
+            keep.resize(all);
+            for (uint32_t s = 0; s < all; s++) keep[s] = s;
+            fwd_work.assign(work.begin() + (std::ptrdiff_t)pos, work.begin() + (std::ptrdiff_t)end);
+            fwd_dists = dists;
+        } else {
+            nd_fwd.clear();
+            for (uint32_t s = 0; s < all; s++) {
+                const uint32_t pid = work[pos + s];
                 dist[pid] = found[s];
                 if (found[s] < 0) continue;
-            } else if (found[s] != dists[s]) {
-                malcs_set_error("pair %u: the backward sweep found distance %d, expected %d (internal error)", pid, found[s], dists[s]);
-                return MALCS_ERR_INTERNAL;
+                keep.push_back(s); fwd_work.push_back(pid); fwd_tab_off.push_back(tab_off[s]);
+                nd_fwd.push_back((int64_t)found[s] + 3);
             }
-            keep.push_back(s); fwd_work.push_back(pid); fwd_tab_off.push_back(tab_off[s]);
-            nd_fwd.push_back((int64_t)found[s] + 3);
+            cntf = (uint32_t)keep.size();
+            if (!cntf) { for (uint32_t s = 0; s < all; s++) out_first[pos + s + 1] = out_runs.size() / 4; pos = end; continue; }
+            fwd_dists.resize(cntf);
+            for (uint32_t f = 0; f < cntf; f++) fwd_dists[f] = found[keep[f]];
+            const uint64_t fr_f2 = fr_layout(nd_fwd, lds_diags, fr_off_f);
+            if (fr_f2 > std::max(fr_b, fr_f)) { malcs_set_error("sweep scratch too small (internal error)"); return MALCS_ERR_INTERNAL; }
+            MALCS_HIP(malcs_h2d(st, d_work.p, fwd_work.data(), cntf * 4ull));
+            MALCS_HIP(malcs_h2d(st, d_dists.p, fwd_dists.data(), cntf * 4ull));
+            MALCS_HIP(malcs_h2d(st, d_tab_off.p, fwd_tab_off.data(), cntf * 8ull));
         }
-        const uint32_t cntf = (uint32_t)keep.size();
-        if (!cntf) { for (uint32_t s = 0; s < all; s++) out_first[pos + s + 1] = out_runs.size() / 4; pos = end; continue; }
-        std::vector<int32_t> fwd_dists(cntf);
-        for (uint32_t f = 0; f < cntf; f++) fwd_dists[f] = found[keep[f]];
-        const uint64_t fr_f2 = fr_layout(nd_fwd, lds_diags, fr_off_f);
-        if (fr_f2 > std::max(fr_b, fr_f)) { malcs_set_error("sweep scratch too small (internal error)"); return MALCS_ERR_INTERNAL; }
-        MALCS_HIP(malcs_h2d(st, d_work.p, fwd_work.data(), cntf * 4ull));
-        MALCS_HIP(malcs_h2d(st, d_dists.p, fwd_dists.data(), cntf * 4ull));
-        MALCS_HIP(malcs_h2d(st, d_tab_off.p, fwd_tab_off.data(), cntf * 8ull));
         std::vector<uint32_t> cap(cntf), got(cntf);
         std::vector<uint64_t> off(cntf);
         uint64_t total = 0;
