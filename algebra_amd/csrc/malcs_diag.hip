@@ -805,6 +805,23 @@ k_llcs_diag(const uint32_t *__restrict__ rows, const uint32_t *__restrict__ piec
         V[k] = rs >= 0 ? ~0u : (rs <= -32 ? 0u : (~0u << -rs));
     }
     p += (NLW - 1) * NP * 64;
+    // the join's table (see there): entry (front nibble | back nibble << 4) = sum << 16 | largest prefix sum of the four
+    // steps front bit - back bit, lowest bit first.  Four entries per lane, worked out HERE, while the wave's first rows
+    // are on their way (behind the wait below it was 0.2 us of every wave's start); a wave's LDS operations complete in
+    // order, so no barrier
+    __shared__ uint32_t join_tab[NLW == 3 && NP == 2 && FUSED ? 256 : 1];
+    if constexpr (NLW == 3 && NP == 2 && FUSED) {
+        if (halves && (info & PIECE_JOINED)) {
+#pragma unroll
+            for (int j = 0; j < 4; j++) {
+                const uint32_t idx = lane * 4u + (uint32_t)j;
+                int t = 0, mp = 0;
+#pragma unroll
+                for (int k = 0; k < 4; k++) { t += (int)((idx >> k) & 1u) - (int)((idx >> (4 + k)) & 1u); mp = max(mp, t); }
+                join_tab[idx] = ((uint32_t)t << 16) | (uint32_t)mp;
+            }
+        }
+    }
     rows_wait(nxt);
 
     uint32_t banked = 0;
@@ -824,20 +841,6 @@ k_llcs_diag(const uint32_t *__restrict__ rows, const uint32_t *__restrict__ piec
         if (halves) {                                  // every block of every lane is plain (the plan saw to that)
             uint32_t ones = 0;
             unsigned long long pre = 0ull;             // the other part's join word, if it was there shortly before the end
-            // the join's table (see there): entry (front nibble | back nibble << 4) = sum << 16 | largest prefix sum of
-            // the four steps front bit - back bit, lowest bit first.  Four entries per lane, worked out while the wave's
-            // first rows are on their way; a wave's LDS operations complete in order, so no barrier
-            __shared__ uint32_t join_tab[256];
-            if (info & PIECE_JOINED) {
-#pragma unroll
-                for (int j = 0; j < 4; j++) {
-                    const uint32_t idx = lane * 4u + (uint32_t)j;
-                    int t = 0, mp = 0;
-#pragma unroll
-                    for (int k = 0; k < 4; k++) { t += (int)((idx >> k) & 1u) - (int)((idx >> (4 + k)) & 1u); mp = max(mp, t); }
-                    join_tab[idx] = ((uint32_t)t << 16) | (uint32_t)mp;
-                }
-            }
             if (info & PIECE_CODES) {
                 __shared__ __attribute__((aligned(4096))) uint32_t lds_masks[16 * 64];
                 diag_halves_lds(V, P, ones, rows_u + (META_ROWS + (NLW - 1) * NP) * 64, lane, nxt, iters, lds_masks,
