@@ -137,6 +137,20 @@ void malcs_pinned_free(void *p)
     for (pinned_block &k : g_pinned) if (k.p == p) { k.used = false; return; }
 }
 
+extern "C" int malcs_host_alloc(uint64_t bytes, void **p)
+{
+    if (!p) { malcs_set_error("NULL argument"); return MALCS_ERR_ARG; }
+    *p = malcs_pinned_alloc(bytes ? bytes : 1);
+    if (!*p) { malcs_set_error("no pinned host memory for %llu bytes", (unsigned long long)bytes); return MALCS_ERR_NOMEM; }
+    return MALCS_OK;
+}
+
+extern "C" int malcs_host_free(void *p)
+{
+    malcs_pinned_free(p);
+    return MALCS_OK;
+}
+
 // ---- pooled device memory ---------------------------------------------------------------------------
 hipError_t malcs_pool_alloc(malcs_ctx *c, void **p, size_t bytes)
 {

@@ -365,8 +365,8 @@ int malcs_relmatrix_tiles_device(const malcs_relmatrix *h, const void **d_labels
 static int relmatrix_assemble(malcs_relmatrix *h, const uint8_t *d_src, uint8_t *full)
 {
     hipStream_t st = h->ctx->stream;
-    dev<uint8_t> d_full;
-    if (d_full.alloc((size_t)h->n * h->n)) { malcs_set_error("device allocation failed (%u x %u labels)", h->n, h->n); return MALCS_ERR_NOMEM; }
+    pool_scoped<uint8_t> d_full(h->ctx);           // from the context's pool: no hipMalloc / hipFree of n x n bytes per matrix
+    if (d_full.alloc((size_t)h->n * h->n) != hipSuccess) { (void)hipGetLastError(); malcs_set_error("device allocation failed (%u x %u labels)", h->n, h->n); return MALCS_ERR_NOMEM; }
     hipLaunchKernelGGL(k_relation_assemble, dim3(h->n, (h->n + 255u) / 256u), dim3(256), 0, st, h->n, h->tile, h->blocks, h->world,
                        h->per_rank, d_src ? d_src : h->labels.p, d_full.p);
     MALCS_HIP(hipGetLastError());

@@ -149,7 +149,7 @@ class LCSgraph:
             res.close()
             raise ValueError("maximum distance exceeded")
         # the graphs share the result handle; it is released when the last of them goes away
-        return [cls._from_arrays(pairs[i][1], res.distance[i], res.supremal[i], result=(res, i)) for i in range(n)]
+        return GraphBatch(cls._from_arrays(pairs[i][1], res.distance[i], res.supremal[i], result=(res, i)) for i in range(n))
 
     @classmethod
     def from_sequence(cls, reference, observed):
@@ -262,7 +262,7 @@ class LCSgraph:
                 else:
                     again.append((idx, reference, allele, off * 2))
             pending = again
-        return results
+        return GraphBatch(results)
 
     def bfs_traversal(self, atomics=False):
         """Generate all (source node, sink node, [variants]) edges in BFS order
@@ -377,6 +377,24 @@ class LCSgraph:
                 masks |= (np.cumsum(span)[:size] > 0).astype(np.uint8) << bit
         self.__dict__["_atoms"] = (lo, masks)
         return self.__dict__["_atoms"]
+
+
+class GraphBatch(list):
+    """What the batch constructors return: a list of graphs that can also keep the per-variant columns the
+    relation matrix reads (intervals, distances, supremal keys, symbol and atom masks: `relations.matrix.columns_of`),
+    so that they are put together once per batch and not once per matrix.  No counterpart in the reference (its
+    graphs are single objects); every list operation works, and the kept columns are dropped as soon as the list no
+    longer holds the graphs they were made from."""
+
+    __slots__ = ("_columns",)
+
+    def columns(self, reference, make):
+        kept = getattr(self, "_columns", None)
+        # tuple comparison stops at identity for every element: 5 000 graphs in ~20 us
+        if kept is None or kept[0] != tuple(self) or kept[1] != reference:
+            kept = (tuple(self), reference, make(reference, self))
+            self._columns = kept
+        return kept[2]
 
 
 def trim(lhs, rhs):

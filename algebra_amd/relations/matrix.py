@@ -113,6 +113,13 @@ def device_inputs(reference, graphs, prep):
     return ref, sup, sup_off, prep.distance, atoms, atom_off
 
 
+def columns_of(reference, graphs):
+    """The per-variant columns of a matrix: (`Prepared`, `device_inputs` or None).  A `GraphBatch` keeps them
+    (`GraphBatch.columns`), so the second matrix over the same batch finds them made."""
+    prep = Prepared(graphs)
+    return prep, device_inputs(reference, graphs, prep)
+
+
 def compare_matrix(reference, graphs, tile=256, comm=None, rank=0, world=1, gather=None, distance_fn=None, stats=None,
                    tiles_cls=None):
     """uint8 matrix L with L[i, j] = code of compare(reference, graphs[i], graphs[j]).
@@ -145,7 +152,10 @@ def compare_matrix(reference, graphs, tile=256, comm=None, rank=0, world=1, gath
             stats["seconds_" + name] = stats.get("seconds_" + name, 0.0) + now - clock[0]
             clock[0] = now
 
-    prep = Prepared(graphs)
+    kept = None
+    if tiles_cls is None and hasattr(graphs, "columns"):        # a GraphBatch: the columns are made once per batch
+        kept = graphs.columns(reference, columns_of)
+    prep = kept[0] if kept else Prepared(graphs)
     lap("prepare")
     if tiles_cls is None:
         from .. import _native
@@ -156,7 +166,10 @@ def compare_matrix(reference, graphs, tile=256, comm=None, rank=0, world=1, gath
         # the pairs the pre-filters leave: on the device when the library can do all of it there (union windows, one
         # batch of distances, distance arithmetic, atom masks -- malcs_relmatrix_decide), else one batch of edit
         # distances over union windows put together here and the verdicts in numpy / Python
-        on_device = device_inputs(reference, graphs, prep) if (tiles_cls is None and hasattr(tiles, "decide")) else None
+        if kept:
+            on_device = kept[1]
+        else:
+            on_device = device_inputs(reference, graphs, prep) if (tiles_cls is None and hasattr(tiles, "decide")) else None
         if on_device is not None:
             lap("device_inputs")
             n_dp = tiles.decide(*on_device, 4)

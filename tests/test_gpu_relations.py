@@ -118,6 +118,44 @@ def test_compare_matrix(tile):
         assert stats["dp_pairs"] > 0
 
 
+def test_compare_matrix_kept_columns():
+    """A batch of graphs keeps the per-variant columns of its matrix (GraphBatch.columns): the second matrix over the
+    same batch re-uses them and gives the same labels, a batch that was changed in between makes them anew, and a
+    sub-list (a plain list) never sees them.  The matrix itself sits in pinned host memory and is an ordinary array."""
+    from algebra_amd.lcs import LCSgraph
+    from algebra_amd.lcs.lcs_graph import GraphBatch
+    from algebra_amd.relations import compare_matrix
+    from algebra_amd.variants import Variant
+    case = SEQS["matrices"][0]
+    want = np.array(case["labels"], dtype=np.uint8)
+    graphs = LCSgraph.from_variant_batch(case["reference"], [[Variant(*v)] for v in case["variants"]])
+    assert isinstance(graphs, GraphBatch) and isinstance(graphs, list)
+    first = compare_matrix(case["reference"], graphs, tile=16)
+    columns = graphs._columns[2]
+    second = compare_matrix(case["reference"], graphs, tile=16)
+    assert graphs._columns[2] is columns
+    assert np.array_equal(first, want) and np.array_equal(second, want)
+    first[0, 0] = 7                                              # writable, and not shared with the next result
+    assert compare_matrix(case["reference"], graphs, tile=16)[0, 0] == 0
+    # the batch changes: two graphs swapped, then one dropped
+    graphs[0], graphs[5] = graphs[5], graphs[0]
+    order = [5] + list(range(1, 5)) + [0] + list(range(6, len(graphs)))
+    assert np.array_equal(compare_matrix(case["reference"], graphs, tile=16), want[np.ix_(order, order)])
+    assert graphs._columns[2] is not columns
+    del graphs[3]
+    order.pop(3)
+    assert np.array_equal(compare_matrix(case["reference"], graphs, tile=16), want[np.ix_(order, order)])
+    part = graphs[2:9]
+    assert type(part) is list
+    assert np.array_equal(compare_matrix(case["reference"], part, tile=16), want[np.ix_(order[2:9], order[2:9])])
+    # another reference of the same length is another matrix: the columns kept for the first must not be used
+    other = case["reference"][::-1]
+    graphs2 = LCSgraph.from_variant_batch(other, [[Variant(*v)] for v in case["variants"]])
+    plain = compare_matrix(other, list(graphs2), tile=16)
+    compare_matrix(other, graphs2, tile=16)
+    assert np.array_equal(compare_matrix(other, graphs2, tile=16), plain)
+
+
 def test_from_variant_batch_equals_singles():
     from algebra_amd.lcs import LCSgraph
     from algebra_amd.variants import Variant
