@@ -220,6 +220,7 @@ static void ctx_release(malcs_ctx *c)
     if (c->ev0) hipEventDestroy(c->ev0);
     if (c->ev1) hipEventDestroy(c->ev1);
     if (c->ev2) hipEventDestroy(c->ev2);
+    if (c->copy_stream) hipStreamDestroy(c->copy_stream);
     if (c->stream) hipStreamDestroy(c->stream);
     delete c;
 }

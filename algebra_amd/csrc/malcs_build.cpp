@@ -571,47 +571,78 @@ static int gbuild_hook(void *user_, const malcs_sweep_chunk &c)
     MALCS_HIP(malcs_h2d(st, d_slots.p, slots.data(), n_slots * sizeof(uint32_t)));
     MALCS_HIP(malcs_h2d(st, d_scratch_off.p, scratch_off.data(), (size_t)c.count * sizeof(uint64_t)));
     MALCS_HIP(hipMemsetAsync(d_cursor.p, 0, sizeof(unsigned long long), st));
+    // The kernels run group by group (the small graphs in up to four groups, then the large ones) and say after every
+    // group how far the output has grown: while a group is being built, the words of the one before travel home on the
+    // context's second stream (104 MB for 100 000 C2 graphs: 1.9 ms that used to follow the 2.5 ms of the kernels).
+    if (!ctx->copy_stream) MALCS_HIP(hipStreamCreateWithFlags(&ctx->copy_stream, hipStreamNonBlocking));
+    struct group { size_t first, count; bool small; };
+    std::vector<group> groups;
+    {
+        const size_t parts = small.size() >= 4096 ? 4 : 1, per = (small.size() + parts - 1) / parts;
+        for (size_t at = 0; at < small.size(); at += per) groups.push_back({at, std::min(per, small.size() - at), true});
+        if (!big.empty()) groups.push_back({small.size(), big.size(), false});
+    }
+    struct event_set {
+        std::vector<hipEvent_t> ev;
+        ~event_set() { for (hipEvent_t e : ev) (void)hipEventDestroy(e); }
+    } done;
+    pinned_vec<unsigned long long> grown;
+    grown.resize(groups.size());
     MALCS_HIP(hipEventRecord(ctx->ev1, st));
-    int rc = malcs_gbuild_launch(ctx, true, c.d_runs, c.d_run_off, c.d_run_cnt, c.d_pids, d_slots.p, (uint32_t)small.size(), u.b->d_a_len, u.b->d_b_len,
-                                 u.b->d_dist, u.d_shift, d_scratch.p, d_scratch_off.p, d_words.p, out_cap, d_cursor.p, d_pair_out.p);
-    if (rc) return rc;
-    rc = malcs_gbuild_launch(ctx, false, c.d_runs, c.d_run_off, c.d_run_cnt, c.d_pids, d_slots.p + small.size(), (uint32_t)big.size(), u.b->d_a_len,
-                             u.b->d_b_len, u.b->d_dist, u.d_shift, d_scratch.p, d_scratch_off.p, d_words.p, out_cap, d_cursor.p, d_pair_out.p);
-    if (rc) return rc;
+    for (size_t k = 0; k < groups.size(); k++) {
+        const int rc = malcs_gbuild_launch(ctx, groups[k].small, c.d_runs, c.d_run_off, c.d_run_cnt, c.d_pids, d_slots.p + groups[k].first,
+                                           (uint32_t)groups[k].count, u.b->d_a_len, u.b->d_b_len, u.b->d_dist, u.d_shift, d_scratch.p,
+                                           d_scratch_off.p, d_words.p, out_cap, d_cursor.p, d_pair_out.p);
+        if (rc) return rc;
+        MALCS_HIP(hipMemcpyAsync(&grown.data()[k], d_cursor.p, sizeof(unsigned long long), hipMemcpyDeviceToHost, st));
+        hipEvent_t e = nullptr;
+        MALCS_HIP(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+        done.ev.push_back(e);
+        MALCS_HIP(hipEventRecord(e, st));
+    }
     MALCS_HIP(hipEventRecord(ctx->ev2, st));
     pinned_vec<int32_t> pair_out;
     pair_out.resize((size_t)c.count * PO);
-    unsigned long long used = 0;
     MALCS_HIP(hipMemcpyAsync(pair_out.data(), d_pair_out.p, pair_out.size() * sizeof(int32_t), hipMemcpyDeviceToHost, st));
-    MALCS_HIP(malcs_d2h(st, &used, d_cursor.p, sizeof(used)));
+    // group k's words are [reach[k], reach[k + 1]) of the device buffer and all of home[k]
+    std::vector<uint64_t> reach(groups.size() + 1, 0);
+    std::vector<const int32_t *> home(groups.size(), nullptr);
+    for (size_t k = 0; k < groups.size(); k++) {
+        MALCS_HIP(hipEventSynchronize(done.ev[k]));
+        reach[k + 1] = std::max<uint64_t>(reach[k], std::min<unsigned long long>(grown.data()[k], out_cap));
+        const uint64_t words_k = reach[k + 1] - reach[k];
+        u.out->dev_words.emplace_back();
+        pinned_vec<int32_t> &words = u.out->dev_words.back();
+        words.resize((size_t)words_k);
+        home[k] = words.data();
+        if (words_k)
+            MALCS_HIP(hipMemcpyAsync(words.data(), d_words.p + reach[k], (size_t)words_k * sizeof(int32_t), hipMemcpyDeviceToHost, ctx->copy_stream));
+    }
     MALCS_HIP(malcs_sync(st));
     float ms = 0;
     MALCS_HIP(hipEventElapsedTime(&ms, ctx->ev1, ctx->ev2));
     u.out->timing[3] += ms;
     stages.lap("kernels, counts home");
-    used = std::min<unsigned long long>(used, out_cap);
-    u.out->dev_words.emplace_back();
-    pinned_vec<int32_t> &words = u.out->dev_words.back();
-    words.resize((size_t)used);
-    if (used) {
-        MALCS_HIP(hipMemcpyAsync(words.data(), d_words.p, (size_t)used * sizeof(int32_t), hipMemcpyDeviceToHost, st));
-        MALCS_HIP(malcs_sync(st));
-    }
+    MALCS_HIP(hipStreamSynchronize(ctx->copy_stream));
     stages.lap("graphs home");
-    for (uint32_t f : slots) {
-        const int32_t *po = pair_out.data() + (size_t)f * PO;
-        if (po[0] != 0) continue;                                         // given up: the host half builds this one
-        const uint64_t at = (uint64_t)(uint32_t)po[7] | ((uint64_t)(uint32_t)po[8] << 32);
-        const uint64_t n_nodes = (uint64_t)po[1], n_edges = (uint64_t)po[2];
-        if (at + 3 * n_nodes + 6 * n_edges > used) continue;
-        pair_graph &G = u.out->g[c.pids[f]];
-        const int64_t sh = u.shift ? u.shift[c.pids[f]] : 0;
-        G.dev_nodes = words.data() + at; G.dev_edges = words.data() + at + 3 * n_nodes;
-        G.dev_n_nodes = (int64_t)n_nodes; G.dev_n_edges = (int64_t)n_edges; G.dev_shift = sh;
-        G.supremal[0] = po[3] + sh; G.supremal[1] = po[4] + sh; G.supremal[2] = po[5]; G.supremal[3] = po[6];
-        G.dev_built = true;
-        G.narrow = true;
-        u.out->n_dev_built++;
+    for (size_t k = 0; k < groups.size(); k++) {
+        for (size_t q = groups[k].first; q < groups[k].first + groups[k].count; q++) {
+            const uint32_t f = slots[q];
+            const int32_t *po = pair_out.data() + (size_t)f * PO;
+            if (po[0] != 0) continue;                                     // given up: the host half builds this one
+            const uint64_t at = (uint64_t)(uint32_t)po[7] | ((uint64_t)(uint32_t)po[8] << 32);
+            const uint64_t n_nodes = (uint64_t)po[1], n_edges = (uint64_t)po[2];
+            if (at < reach[k] || at + 3 * n_nodes + 6 * n_edges > reach[k + 1]) continue;
+            pair_graph &G = u.out->g[c.pids[f]];
+            const int64_t sh = u.shift ? u.shift[c.pids[f]] : 0;
+            const int32_t *words = home[k] + (at - reach[k]);
+            G.dev_nodes = words; G.dev_edges = words + 3 * n_nodes;
+            G.dev_n_nodes = (int64_t)n_nodes; G.dev_n_edges = (int64_t)n_edges; G.dev_shift = sh;
+            G.supremal[0] = po[3] + sh; G.supremal[1] = po[4] + sh; G.supremal[2] = po[5]; G.supremal[3] = po[6];
+            G.dev_built = true;
+            G.narrow = true;
+            u.out->n_dev_built++;
+        }
     }
     return MALCS_OK;
 }

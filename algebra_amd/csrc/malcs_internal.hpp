@@ -55,6 +55,7 @@ struct staged_copy { void *dst; const void *src; size_t bytes; };
 struct malcs_ctx {
     int device = -1;
     hipStream_t stream = nullptr;
+    hipStream_t copy_stream = nullptr;     // made when first needed: results that travel home while the next kernels run
     hipEvent_t ev0 = nullptr, ev1 = nullptr, ev2 = nullptr;
     hipDeviceProp_t prop;
     // pinned staging for the many small parameter / result copies of a call (a copy from or to pageable memory

@@ -137,6 +137,12 @@ def extra_configs(ctx, _native, gen):
                                       "reach_ms": round(float(g.timing[1]), 3), "host_build_ms": round(float(g.timing[2]), 1),
                                       "tie_bit_GB_per_s": {"forward_write": round(n * 1e6 * 0.25 / (float(g.timing[0]) * 1e-3) / 1e9, 1),
                                                            "reach_read": round(n * 1e6 * 0.25 / (float(g.timing[1]) * 1e-3) / 1e9, 1)}}
+    # family 2's own roofline (HBM): 0.25 B of tie bits per cell written by the forward pass, read by the
+    # backward pass; 1e6 cells per pair; stage times by HIP events on the library's stream (all launches of the stage)
+    for stage, key, kernel in (("forward", "forward_ms", "k_lcs_forward<W,2,BAND>"), ("reach", "reach_ms", "k_lcs_reach<W,2,BAND>")):
+        gbs = n * 1e6 * 0.25 / (out["c2_lcs_graphs_bitvector"][key] * 1e-3) / 1e9
+        out["c2_lcs_graphs_bitvector"]["roofline_" + stage] = {"bound": "hbm", "kernel": kernel, "achieved": round(gbs, 1), "peak": 8000.0,
+                                                                "unit": "GB/s", "frac": round(gbs / 8000.0, 4)}
     g.close()
     batch.close()
     return out
