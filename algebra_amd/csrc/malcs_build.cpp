@@ -40,7 +40,7 @@ int malcs_sweep_optimal_runs(malcs_batch *b, bool small, const std::vector<uint3
                              pinned_vec<uint32_t> &out_runs, std::vector<uint64_t> &out_first, float *ms,
                              malcs_sweep_hook hook = nullptr, void *hook_user = nullptr);
 int malcs_gbuild_pair_out_words();
-int malcs_gbuild_launch(malcs_ctx *ctx, bool small, uint4 *d_runs, const uint64_t *d_run_off, const uint32_t *d_run_cnt,
+int malcs_gbuild_launch(malcs_ctx *ctx, int kind, uint4 *d_runs, const uint64_t *d_run_off, const uint32_t *d_run_cnt,
                         const uint32_t *d_pids, const uint32_t *d_slots, uint32_t n_slots, const uint32_t *d_a_len,
                         const uint32_t *d_b_len, const int32_t *d_dist, const int64_t *d_shift, int32_t *d_scratch,
                         const uint64_t *d_scratch_off, int32_t *d_out_words, uint64_t out_cap, unsigned long long *d_out_cursor,
@@ -546,19 +546,20 @@ static int gbuild_hook(void *user_, const malcs_sweep_chunk &c)
     malcs_ctx *ctx = u.b->ctx;
     hipStream_t st = ctx->stream;
     const int PO = malcs_gbuild_pair_out_words();
-    std::vector<uint32_t> small, big;
+    std::vector<uint32_t> tiny, small, big;
     std::vector<uint64_t> scratch_off(c.count, 0);
     uint64_t scratch_words = 0, out_cap = 0;
     for (uint32_t f = 0; f < c.count; f++) {
         const uint32_t R = c.cnt[f], pid = c.pids[f];
         if (R == 0 || u.b->a_len[pid] >= (1u << 30) || u.b->b_len[pid] >= (1u << 30)) continue;
-        if (R <= 64) small.push_back(f);
+        if (R <= 32) tiny.push_back(f);
+        else if (R <= 64) small.push_back(f);
         else if (R <= 1024) { big.push_back(f); scratch_off[f] = scratch_words; scratch_words += (uint64_t)malcs_core::arena_words(2 * (int32_t)R + 16, 8 * (int32_t)R + 64, (int32_t)R + 8); }
         else continue;
         out_cap += 3ull * (2ull * R + 8) + 6ull * (4ull * R + 16);      // more than graphs of R runs usually need; beyond it the host builds
     }
-    if (small.empty() && big.empty()) return MALCS_OK;
-    const size_t n_slots = small.size() + big.size();
+    if (tiny.empty() && small.empty() && big.empty()) return MALCS_OK;
+    const size_t n_slots = tiny.size() + small.size() + big.size();
     pool_scoped<uint32_t> d_slots(ctx);
     pool_scoped<uint64_t> d_scratch_off(ctx);
     pool_scoped<int32_t> d_scratch(ctx), d_words(ctx), d_pair_out(ctx);
@@ -566,21 +567,23 @@ static int gbuild_hook(void *user_, const malcs_sweep_chunk &c)
     MALCS_HIP(d_slots.alloc(n_slots)); MALCS_HIP(d_scratch_off.alloc(c.count)); MALCS_HIP(d_scratch.alloc(std::max<uint64_t>(scratch_words, 1)));
     MALCS_HIP(d_words.alloc(out_cap)); MALCS_HIP(d_pair_out.alloc((size_t)c.count * PO)); MALCS_HIP(d_cursor.alloc(1));
     stages.lap("classes, allocations");
-    std::vector<uint32_t> slots(small);
+    std::vector<uint32_t> slots(tiny);
+    slots.insert(slots.end(), small.begin(), small.end());
     slots.insert(slots.end(), big.begin(), big.end());
     MALCS_HIP(malcs_h2d(st, d_slots.p, slots.data(), n_slots * sizeof(uint32_t)));
     MALCS_HIP(malcs_h2d(st, d_scratch_off.p, scratch_off.data(), (size_t)c.count * sizeof(uint64_t)));
     MALCS_HIP(hipMemsetAsync(d_cursor.p, 0, sizeof(unsigned long long), st));
-    // The kernels run group by group (the small graphs in up to four groups, then the large ones) and say after every
+    // The kernels run group by group (the graphs of at most 32 runs in up to four groups, then those of up to 64, then the large ones) and say after every
     // group how far the output has grown: while a group is being built, the words of the one before travel home on the
     // context's second stream (104 MB for 100 000 C2 graphs: 1.9 ms that used to follow the 2.5 ms of the kernels).
     if (!ctx->copy_stream) MALCS_HIP(hipStreamCreateWithFlags(&ctx->copy_stream, hipStreamNonBlocking));
-    struct group { size_t first, count; bool small; };
+    struct group { size_t first, count; int kind; };
     std::vector<group> groups;
     {
-        const size_t parts = small.size() >= 4096 ? 4 : 1, per = (small.size() + parts - 1) / parts;
-        for (size_t at = 0; at < small.size(); at += per) groups.push_back({at, std::min(per, small.size() - at), true});
-        if (!big.empty()) groups.push_back({small.size(), big.size(), false});
+        const size_t parts = tiny.size() >= 4096 ? 4 : 1, per = (tiny.size() + parts - 1) / parts;
+        for (size_t at = 0; at < tiny.size(); at += per) groups.push_back({at, std::min(per, tiny.size() - at), 0});
+        if (!small.empty()) groups.push_back({tiny.size(), small.size(), 1});
+        if (!big.empty()) groups.push_back({tiny.size() + small.size(), big.size(), 2});
     }
     struct event_set {
         std::vector<hipEvent_t> ev;
@@ -590,7 +593,7 @@ static int gbuild_hook(void *user_, const malcs_sweep_chunk &c)
     grown.resize(groups.size());
     MALCS_HIP(hipEventRecord(ctx->ev1, st));
     for (size_t k = 0; k < groups.size(); k++) {
-        const int rc = malcs_gbuild_launch(ctx, groups[k].small, c.d_runs, c.d_run_off, c.d_run_cnt, c.d_pids, d_slots.p + groups[k].first,
+        const int rc = malcs_gbuild_launch(ctx, groups[k].kind, c.d_runs, c.d_run_off, c.d_run_cnt, c.d_pids, d_slots.p + groups[k].first,
                                            (uint32_t)groups[k].count, u.b->d_a_len, u.b->d_b_len, u.b->d_dist, u.d_shift, d_scratch.p,
                                            d_scratch_off.p, d_words.p, out_cap, d_cursor.p, d_pair_out.p);
         if (rc) return rc;

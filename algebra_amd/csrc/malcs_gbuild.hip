@@ -109,15 +109,21 @@ k_graph_build(uint4 *__restrict__ runs, const uint64_t *__restrict__ run_off, co
 
 int malcs_gbuild_pair_out_words() { return PAIR_OUT; }
 
-// small: graphs of at most 64 runs on an arena in LDS; otherwise at most 1 024 runs on an arena in `scratch`
-int malcs_gbuild_launch(malcs_ctx *ctx, bool small, uint4 *d_runs, const uint64_t *d_run_off, const uint32_t *d_run_cnt,
+// kind 0: graphs of at most 32 runs on a small arena in LDS (7.5 KB per wave: twice as many waves per CU as kind 1, and
+// the construction is a chain of dependent LDS accesses that only other waves can hide; 99 % of the graphs of 1 kb
+// windows at 2 % indels); kind 1: at most 64 runs, LDS arena of 13.5 KB; kind 2: at most 1 024 runs on an arena in `scratch`
+int malcs_gbuild_launch(malcs_ctx *ctx, int kind, uint4 *d_runs, const uint64_t *d_run_off, const uint32_t *d_run_cnt,
                         const uint32_t *d_pids, const uint32_t *d_slots, uint32_t n_slots, const uint32_t *d_a_len,
                         const uint32_t *d_b_len, const int32_t *d_dist, const int64_t *d_shift, int32_t *d_scratch,
                         const uint64_t *d_scratch_off, int32_t *d_out_words, uint64_t out_cap, unsigned long long *d_out_cursor,
                         int32_t *d_pair_out)
 {
     if (!n_slots) return MALCS_OK;
-    if (small)
+    if (kind == 0)
+        hipLaunchKernelGGL((k_graph_build<32, true, 64, 160, 40>), dim3(n_slots), dim3(64), 0, ctx->stream, d_runs, d_run_off, d_run_cnt,
+                           d_pids, d_slots, n_slots, d_a_len, d_b_len, d_dist, d_shift, d_scratch, d_scratch_off, d_out_words,
+                           (unsigned long long)out_cap, d_out_cursor, d_pair_out);
+    else if (kind == 1)
         hipLaunchKernelGGL((k_graph_build<64, true, 112, 288, 72>), dim3(n_slots), dim3(64), 0, ctx->stream, d_runs, d_run_off, d_run_cnt,
                            d_pids, d_slots, n_slots, d_a_len, d_b_len, d_dist, d_shift, d_scratch, d_scratch_off, d_out_words,
                            (unsigned long long)out_cap, d_out_cursor, d_pair_out);
