@@ -415,7 +415,10 @@ def pinned_empty(shape, dtype=np.uint8):
     speed (a pageable array of 25 MB costs 2.5 ms, this one 0.5)."""
     dtype = np.dtype(dtype)
     count = int(np.prod(shape, dtype=np.int64))
-    block = _PinnedBlock(max(count * dtype.itemsize, 1))
+    try:
+        block = _PinnedBlock(max(count * dtype.itemsize, 1))
+    except MalcsError:                      # pinned memory is a scarce kind: a caller who holds many results gets pageable ones
+        return np.empty(shape, dtype=dtype)
     return np.asarray(block)[:count * dtype.itemsize].view(dtype).reshape(shape)
 
 
