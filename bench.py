@@ -132,7 +132,7 @@ def extra_configs(ctx, _native, gen):
     g.close()
     batch.close()
     # the same shape through the bit-vector kernels (what divergent windows use): HBM-bound tie-bit rows
-    n = 20000
+    n = 100000                                                 # 25 GB of tie bits each way (3.0 / 3.8 TB/s; 20 000 pairs: 2.7 / 2.9)
     os.environ["MALCS_SWEEP_DMAX"] = "-1"
     batch = _native.Batch(ctx, *gen.c2_batch(n, seed=12), 4)
     batch.graphs().close()

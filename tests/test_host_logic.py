@@ -142,3 +142,31 @@ def test_shard_partition():
     for world in (1, 2, 3, 8):
         parts = [shard(tiles, r, world) for r in range(world)]
         assert sorted(t for p in parts for t in p) == sorted(tiles)
+
+
+def test_graph_batch_keeps_columns_only_while_it_holds_the_same_graphs():
+    """GraphBatch (what the batch constructors return) is a list that keeps the per-variant columns of its matrix: made
+    once, found again for the same graphs and reference, made anew after any change of either."""
+    from algebra_amd.lcs.lcs_graph import GraphBatch
+    made = []
+
+    def make(reference, graphs):
+        made.append((reference, tuple(graphs)))
+        return len(made)
+
+    items = [object() for _ in range(5)]
+    batch = GraphBatch(items)
+    assert isinstance(batch, list) and batch == items
+    assert batch.columns("ACGT", make) == 1
+    assert batch.columns("ACGT", make) == 1 and len(made) == 1
+    assert batch.columns("ACGA", make) == 2                      # another reference
+    assert batch.columns("ACGA", make) == 2
+    batch[1], batch[2] = batch[2], batch[1]                      # same graphs, another order
+    assert batch.columns("ACGA", make) == 3
+    batch.append(object())
+    assert batch.columns("ACGA", make) == 4
+    batch.pop()
+    assert batch.columns("ACGA", make) == 5                      # what was kept belonged to six graphs
+    assert batch.columns("ACGA", make) == 5
+    assert type(batch[1:3]) is list and type(batch + batch) is list and not hasattr(batch[1:3], "columns")
+    assert GraphBatch().columns("", make) == 6
