@@ -88,7 +88,7 @@ class LCSgraph:
         (Graphs handle, pair index) to fetch them from on demand."""
         self = cls.__new__(cls)
         self.distance = int(distance)
-        start, end, lo, hi = (int(x) for x in supremal)
+        start, end, lo, hi = supremal if type(supremal) is list else (int(x) for x in supremal)
         self.supremal = Variant(start, end, observed[lo:hi])
         self._observed = observed
         self._result = result
@@ -149,7 +149,8 @@ class LCSgraph:
             res.close()
             raise ValueError("maximum distance exceeded")
         # the graphs share the result handle; it is released when the last of them goes away
-        return GraphBatch(cls._from_arrays(pairs[i][1], res.distance[i], res.supremal[i], result=(res, i)) for i in range(n))
+        distance, supremal = res.distance.tolist(), res.supremal.tolist()      # Python ints once, not per graph
+        return GraphBatch(cls._from_arrays(pairs[i][1], distance[i], supremal[i], result=(res, i)) for i in range(n))
 
     @classmethod
     def from_sequence(cls, reference, observed):
@@ -232,9 +233,12 @@ class LCSgraph:
             if not variants:
                 trivial.append(idx)
                 continue
-            start = min(v.start for v in variants)
-            end = max(v.end for v in variants)
-            observed = patch(reference[start:end], [Variant(v.start - start, v.end - start, v.sequence) for v in variants])
+            if len(variants) == 1:                     # one variant: the patched stretch is its sequence
+                start, end, observed = variants[0].start, variants[0].end, variants[0].sequence
+            else:
+                start = min(v.start for v in variants)
+                end = max(v.end for v in variants)
+                observed = patch(reference[start:end], [Variant(v.start - start, v.end - start, v.sequence) for v in variants])
             if reference[start:end] == observed:
                 trivial.append(idx)
                 continue
