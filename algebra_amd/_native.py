@@ -60,6 +60,7 @@ def _load():
         "malcs_graphs_counts": (c.c_int, [vp, vp]),
         "malcs_graphs_status": (c.c_int, [vp, vp, vp]),
         "malcs_graphs_supremal": (c.c_int, [vp, vp]),
+        "malcs_graphs_columns": (c.c_int, [vp, vp, vp, vp, vp]),
         "malcs_graphs_runs": (c.c_int, [vp, u64, vp]),
         "malcs_graphs_nodes": (c.c_int, [vp, u64, vp]),
         "malcs_graphs_edges": (c.c_int, [vp, u64, vp]),
@@ -292,15 +293,16 @@ class Graphs:
         self.n_pairs = n_pairs
         _live["graphs"].add(self)
         try:
-            self.counts = np.zeros((n_pairs, 4), dtype=np.int64)
-            self.status = np.zeros(n_pairs, dtype=np.int32)
-            self.distance = np.zeros(n_pairs, dtype=np.int64)
-            self.supremal = np.zeros((n_pairs, 4), dtype=np.int64)
+            # large handles read their columns into recycled pinned blocks: pages that exist already (fresh numpy
+            # arrays of 100 000 pairs cost 0.5 ms of page faults), filled in one pass over the pairs
+            empty = pinned_empty if n_pairs >= 4096 else np.empty
+            self.counts = empty((n_pairs, 4), dtype=np.int64)
+            self.status = empty(n_pairs, dtype=np.int32)
+            self.distance = empty(n_pairs, dtype=np.int64)
+            self.supremal = empty((n_pairs, 4), dtype=np.int64)
             self.timing = np.zeros(3, dtype=np.float32)
             if n_pairs:
-                check(lib.malcs_graphs_counts(handle, ptr(self.counts)))
-                check(lib.malcs_graphs_status(handle, ptr(self.status), ptr(self.distance)))
-                check(lib.malcs_graphs_supremal(handle, ptr(self.supremal)))
+                check(lib.malcs_graphs_columns(handle, ptr(self.counts), ptr(self.status), ptr(self.distance), ptr(self.supremal)))
             check(lib.malcs_graphs_timing(handle, ptr(self.timing)))
             built, ms = ctypes.c_uint64(), ctypes.c_float()
             check(lib.malcs_graphs_device_built(handle, ctypes.byref(built), ctypes.byref(ms)))

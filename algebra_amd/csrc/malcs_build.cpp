@@ -1165,6 +1165,22 @@ int malcs_graphs_counts(const malcs_graphs *g, int64_t *counts)
     return MALCS_OK;
 }
 
+// counts, status, distance and supremal in one pass over the pairs (a handle of 100 000 graphs is 20 MB of per-pair
+// records: three passes cost three times the memory traffic)
+int malcs_graphs_columns(const malcs_graphs *g, int64_t *counts, int32_t *status, int64_t *distance, int64_t *supremal4)
+{
+    if (!g || !counts || !status || !distance || !supremal4) { malcs_set_error("NULL argument"); return MALCS_ERR_ARG; }
+    for (size_t i = 0; i < g->g.size(); i++) {
+        const pair_graph &G = g->g[i];
+        counts[4 * i] = (int64_t)G.n_runs(); counts[4 * i + 1] = G.n_levels;
+        counts[4 * i + 2] = (int64_t)G.n_nodes(); counts[4 * i + 3] = (int64_t)G.n_edges();
+        status[i] = G.status;
+        distance[i] = G.distance;
+        for (int k = 0; k < 4; k++) supremal4[4 * i + k] = G.supremal[k];
+    }
+    return MALCS_OK;
+}
+
 int malcs_graphs_status(const malcs_graphs *g, int32_t *status, int64_t *distance)
 {
     if (!g) { malcs_set_error("NULL argument"); return MALCS_ERR_ARG; }
