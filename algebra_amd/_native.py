@@ -261,10 +261,11 @@ class Batch:
         return out
 
     def plan_info(self):
-        info = (ctypes.c_uint64 * 8)()
+        info = (ctypes.c_uint64 * 16)()
         check(lib.malcs_batch_plan_info(self.handle, info))
         keys = ("window_pairs", "window_limbs", "window_threshold", "window_cells", "full_cells", "full_classes",
-                "window_tiles", "two_limb_tiles")
+                "window_tiles", "two_limb_tiles", "pieces", "cut_tiles", "workgroups", "window_cells_unpadded",
+                "sample_mean_x16", "sample_sd_x16", "worst_simd", "balanced_cuts")
         return dict(zip(keys, (int(x) for x in info)))
 
     def lcs_nodes(self, shift=None, max_distance=None):

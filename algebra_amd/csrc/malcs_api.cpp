@@ -613,7 +613,7 @@ int malcs_batch_replan(malcs_batch *b)
 {
     if (!b) { malcs_set_error("batch is NULL"); return MALCS_ERR_ARG; }
     MALCS_HIP(hipSetDevice(b->ctx->device));
-    return malcs_dist_plan(b);
+    return malcs_dist_replan(b);
 }
 
 int malcs_edit_distance_launch(malcs_batch *b)
@@ -684,12 +684,29 @@ int malcs_edit_distance_kernel_durations(malcs_batch *b, int iters, float *ms_ea
     return rc;
 }
 
-int malcs_batch_plan_info(const malcs_batch *b, uint64_t *info)
+int malcs_batch_plan_info(malcs_batch *b, uint64_t *info)
 {
     if (!b || !info) { malcs_set_error("NULL argument"); return MALCS_ERR_ARG; }
-    info[0] = b->diag.n_pairs; info[1] = (uint64_t)b->diag.nlw; info[2] = (uint64_t)b->diag.T;
-    info[3] = b->diag.window_cells; info[4] = b->full_cells; info[5] = b->dist_buckets.size();
-    info[6] = b->diag.n_tiles; info[7] = b->diag.n_half_tiles;
+    MALCS_HIP(hipSetDevice(b->ctx->device));
+    uint32_t st[PS_FIELDS];
+    const int rc = malcs_diag_stats(b, st);                      // what the plan decided stays on the device until somebody asks
+    if (rc) return rc;
+    const diag_plan &d = b->diag;
+    const bool all_half = d.nlw && st[PS_NHALF] == d.n_tiles;
+    const uint64_t cols0 = (uint64_t)st[PS_COLS0_HI] << 32 | st[PS_COLS0_LO], cols1 = (uint64_t)st[PS_COLS1_HI] << 32 | st[PS_COLS1_LO];
+    // cells as laid out: rows of a tile's mode x 32 columns x its blocks x its pairs (the last tile may hold fewer than 64)
+    const uint64_t rows3 = 32ull * (uint64_t)d.nlw, missing = d.n_pairs % 64u ? 64u - d.n_pairs % 64u : 0u;
+    uint64_t cells = 0;
+    if (d.nlw) cells = 32ull * 64ull * (64ull * st[PS_BLOCKS_HALF] + rows3 * (st[PS_BLOCKS] - st[PS_BLOCKS_HALF]))
+                       - 32ull * missing * st[PS_IT_LAST] * (st[PS_LAST_HALF] ? 64ull : rows3);
+    info[0] = d.n_pairs; info[1] = (uint64_t)d.nlw; info[2] = (uint64_t)(all_half ? 48 : d.T);
+    info[3] = cells; info[4] = b->full_cells; info[5] = b->dist_buckets.size();
+    info[6] = d.n_tiles; info[7] = st[PS_NHALF];
+    info[8] = st[PS_NPIECES]; info[9] = st[PS_NCUT]; info[10] = d.n_launch;
+    // the cells between the common ends, as they are (no growth to whole blocks or to the tile's longest): columns of
+    // either group x the rows its mode computes
+    info[11] = cols0 * (st[PS_HALFMODE] ? 64ull : rows3) + cols1 * rows3;
+    info[12] = st[PS_SAMPLE_MEAN_X16]; info[13] = st[PS_SAMPLE_SD_X16]; info[14] = st[PS_WORST]; info[15] = st[PS_BALANCED];
     return MALCS_OK;
 }
 

@@ -32,6 +32,7 @@
 // the full-matrix kernel spends 4 * ceil(m / 32) + 2 on (130 for 1 kb).
 #include "malcs_internal.hpp"
 #include "malcs_device.hpp"
+#include "malcs_bitpar.hpp"
 #include "malcs_hostpack.hpp"
 #include <hip/hip_ext.h>
 #include <algorithm>
@@ -50,275 +51,7 @@ using namespace malcs_dev;
 constexpr int META_ROWS = 4;          // pid, m, n, kmax | retry class << 16
 constexpr int MALCS_DIAG_HALF_T = 48; // two limbs moving 16 rows per 16 columns: 64 - 16 diagonals
 
-// ---- the plan, on the device ---------------------------------------------------------------------
-// What a batch needs before its window class can run: the common ends of every pair (they do not change the distance,
-// so they stay out of the window), the pairs sorted by what is left, cut into tiles of 64 lanes, the tiles cut into the
-// pieces that run as workgroups, and the rows of every piece.  Everything that touches pairs runs here, on the packed
-// planes; the host only sees a histogram of lengths (one small copy, the plan's only synchronisation) and works out
-// tiles and pieces from it.
-//
-// items: nine arrays of `count` dwords, one entry per pair of the class (in the order of `pairs`)
-enum { IT_PO, IT_TO, IT_M, IT_N, IT_Q, IT_MT, IT_NT, IT_DELTA, IT_ITERS, ITEM_FIELDS };
-// One record of 16 dwords per pair (half a 128-byte line): the layout kernel reads the records through the sort's
-// permutation, and with a table per field every field of every pair was a line of its own (230 MB of the 436 MB that
-// kernel fetched per C2 batch, FETCH_SIZE).
-constexpr uint32_t ITEM_STRIDE = 16;
-#define ITEM_AT(field, i) item[(size_t)(i) * ITEM_STRIDE + (field)]
-
-// One lane per pair: common prefix / suffix from the planes (XOR of whole words, first / last differing bit), what is left
-// of the pair after the cut, and the histogram of block counts the tiles are formed from (two groups: length
-// differences the two-limb mode holds, and the others).
-template <int NP>
-__global__ void __launch_bounds__(256)
-k_plan_ends(const uint32_t *__restrict__ planes, const uint32_t *__restrict__ a_off, const uint32_t *__restrict__ a_len,
-            const uint32_t *__restrict__ b_off, const uint32_t *__restrict__ b_len, const uint32_t *__restrict__ pairs,
-            uint32_t count, uint32_t min_rows, int trim, uint32_t hist_stride, uint32_t *__restrict__ item, uint32_t *__restrict__ hist)
-{
-    // a hundred thousand pairs of seven different lengths: the workgroup counts in LDS first (2 * hist_stride bins,
-    // dynamic), then adds its non-empty bins to the histogram in memory
-    extern __shared__ uint32_t lds_hist[];
-    for (uint32_t k = threadIdx.x; k < 2u * hist_stride; k += blockDim.x) lds_hist[k] = 0u;
-    __syncthreads();
-    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i < count) {
-    const uint32_t pid = pairs[i];
-    const uint32_t la = a_len[pid], lb = b_len[pid];
-    const bool a_short = la <= lb;
-    uint32_t m = a_short ? la : lb, n = a_short ? lb : la;
-    uint32_t po = a_short ? a_off[pid] : b_off[pid], to = a_short ? b_off[pid] : a_off[pid];
-    uint32_t q = 0, mt = m, nt = n;
-    const uint32_t delta = n - m;
-    if (trim && m > min_rows) {
-        // as LCSgraph.from_sequence cuts them off with trim() (lcs_graph.py:231-235), but never below the rows the
-        // window class needs
-        const uint32_t room = m - min_rows;
-        uint32_t pre = room;
-        for (uint32_t w = 0; 32u * w < room; w++) {
-            uint32_t x = 0;
-#pragma unroll
-            for (int p = 0; p < NP; p++) x |= planes[po + w * NP + p] ^ planes[to + w * NP + p];
-            if (x) { pre = min(room, 32u * w + (uint32_t)__builtin_ctz(x)); break; }
-        }
-        // 32 symbols ending at position e (e >= 32 here: at least min_rows symbols stay in front of the suffix)
-        auto chunk = [&](uint32_t base, uint32_t e, int p) -> uint32_t {
-            const uint32_t at = e - 32u, wd = at >> 5, sh = at & 31u;
-            const uint32_t lo = planes[base + wd * NP + p];
-            return sh ? ((lo >> sh) | (planes[base + (wd + 1u) * NP + p] << (32u - sh))) : lo;
-        };
-        const uint32_t rem = room - pre;
-        uint32_t suf = 0, ea = m, eb = n;
-        while (suf < rem) {
-            uint32_t x = 0;
-#pragma unroll
-            for (int p = 0; p < NP; p++) x |= chunk(po, ea, p) ^ chunk(to, eb, p);
-            const uint32_t c = x ? (uint32_t)__builtin_clz(x) : 32u;
-            suf += min(c, rem - suf);
-            if (c < 32u) break;
-            ea -= 32u; eb -= 32u;
-        }
-        po += (pre >> 5) * NP; to += (pre >> 5) * NP; q = pre & 31u;
-        m -= pre + suf; n -= pre + suf;
-        mt = q + m + suf; nt = q + n + suf;
-    }
-    // a text of whole blocks has no masked last block: both sequences grow by the same symbols at the end (what was cut
-    // off there first, symbol 0 beyond the end: see k_diag_layout)
-    const uint32_t ragged = (32u - (n & 31u)) & 31u;
-    m += ragged; n += ragged;
-    const uint32_t iters = n >> 5;
-    ITEM_AT(IT_PO, i) = po; ITEM_AT(IT_TO, i) = to; ITEM_AT(IT_M, i) = m; ITEM_AT(IT_N, i) = n;
-    ITEM_AT(IT_Q, i) = q; ITEM_AT(IT_MT, i) = mt; ITEM_AT(IT_NT, i) = nt;
-    ITEM_AT(IT_DELTA, i) = delta; ITEM_AT(IT_ITERS, i) = iters;
-    atomicAdd(&lds_hist[(delta > (uint32_t)MALCS_DIAG_HALF_T ? hist_stride : 0u) + iters], 1u);
-    }
-    __syncthreads();
-    for (uint32_t k = threadIdx.x; k < 2u * hist_stride; k += blockDim.x) if (lds_hist[k]) atomicAdd(&hist[k], lds_hist[k]);
-}
-
-// Counting sort by (group, blocks): `cursor` starts as the host's exclusive scan of the histogram (in the order the
-// tiles are formed in); slot s of the sorted order gets the index of its item.  Pairs of equal key may land in any
-// order: they are interchangeable (same block count, same mode).
-__global__ void __launch_bounds__(1024)
-k_plan_scatter(const uint32_t *__restrict__ item, uint32_t count, uint32_t hist_stride, uint32_t *__restrict__ cursor,
-               uint32_t *__restrict__ slot_item)
-{
-    // rank inside the workgroup from LDS counters, one reservation per non-empty key and workgroup from the cursors
-    extern __shared__ uint32_t lds_cnt[];                       // 2 * hist_stride counters, then as many bases
-    uint32_t *lds_base = lds_cnt + 2u * hist_stride;
-    for (uint32_t k = threadIdx.x; k < 2u * hist_stride; k += blockDim.x) lds_cnt[k] = 0u;
-    __syncthreads();
-    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
-    uint32_t key = 0, rank = 0;
-    if (i < count) {
-        key = (ITEM_AT(IT_DELTA, i) > (uint32_t)MALCS_DIAG_HALF_T ? hist_stride : 0u) + ITEM_AT(IT_ITERS, i);
-        rank = atomicAdd(&lds_cnt[key], 1u);
-    }
-    __syncthreads();
-    for (uint32_t k = threadIdx.x; k < 2u * hist_stride; k += blockDim.x) if (lds_cnt[k]) lds_base[k] = atomicAdd(&cursor[k], lds_cnt[k]);
-    __syncthreads();
-    if (i < count) slot_item[lds_base[key] + rank] = i;
-}
-
-// piece_info: blocks of the piece | PIECE_* flags
-constexpr uint32_t PIECE_HALF = 1u << 31;     // two-limb mode (T = 48)
-constexpr uint32_t PIECE_JOINED = 1u << 30;   // one of the two pieces of a tile that was cut: the results meet in the join buffer
-constexpr uint32_t PIECE_BACK = 1u << 29;     // ... the one that runs the reversed sequences from the far end
-constexpr uint32_t PIECE_CODES = 1u << 28;    // two-limb mode with match masks from LDS: the text rows hold 2-bit symbols, not planes
-constexpr uint32_t PIECE_BLOCKS = (1u << 28) - 1u;
-
-// The rows of every piece.  grid = pieces, 256 threads: lane = slot of the tile, the four waves take the rows of the
-// piece in turn.  A piece that runs backwards gets the rows of the reversed pair: pattern row r' is row m - 1 - r',
-// text column j' is column n - 1 - j' (n is whole blocks), i.e. the same words bit-reversed and in reverse order.
-template <int NP>
-__global__ void __launch_bounds__(256)
-k_diag_layout(const uint32_t *__restrict__ planes, const uint32_t *__restrict__ item, uint32_t count,
-              const uint32_t *__restrict__ pairs, const uint8_t *__restrict__ retry_class,
-              const uint32_t *__restrict__ slot_item, const uint32_t *__restrict__ tile_iters,
-              const uint32_t *__restrict__ piece_off, const uint32_t *__restrict__ piece_info,
-              const uint32_t *__restrict__ piece_tile, int nlw, int T, uint32_t *__restrict__ rows)
-{
-    const uint32_t piece = blockIdx.x, lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
-    const uint32_t info = piece_info[piece], tile = piece_tile[piece];
-    const uint32_t nb = info & PIECE_BLOCKS;
-    const bool back = info & PIECE_BACK;
-    const uint32_t n_rows = (uint32_t)(nlw - 1) + nb;
-    const uint32_t idx = slot_item[tile * 64u + lane];
-    uint32_t *out = rows + (size_t)piece_off[piece] * 64u + lane;
-    if (idx == 0xffffffffu) {                                  // an empty slot of the last tile
-        if (wave == 0) { out[0] = 0xffffffffu; out[64] = 0u; out[128] = 0u; out[192] = 0u; }
-        out += META_ROWS * 64;
-        for (uint32_t r = wave; r < n_rows; r += blockDim.x >> 6) {
-            const uint32_t k = r < (uint32_t)(nlw - 1) ? NP : 2 * NP;
-            uint32_t *o = out + (r < (uint32_t)(nlw - 1) ? (size_t)r * NP : (size_t)(nlw - 1) * NP + (size_t)(r - (nlw - 1)) * 2u * NP) * 64u;
-            for (uint32_t j = 0; j < k; j++) o[j * 64u] = 0u;
-        }
-        return;
-    }
-    // pattern (the shorter sequence) and text of the slot, common ends already cut off by k_plan_ends: both start q
-    // symbols (0 ... 31) into the block at po / to and have m / n symbols from there.  Symbols really stored: mt / nt;
-    // m and n reach beyond them: both sequences were lengthened by the same number of symbols to make the text whole
-    // blocks and as long as the longest of its tile, and what lies beyond the end reads as symbol 0 on both sides -- a
-    // common suffix, which does not change the distance.
-    const uint32_t it_tile = tile_iters[tile] & 0x7fffffffu;
-    const bool half = tile_iters[tile] >> 31;
-    const uint32_t grow = 32u * (it_tile - ITEM_AT(IT_ITERS, idx));
-    const uint32_t m = ITEM_AT(IT_M, idx) + grow, n = ITEM_AT(IT_N, idx) + grow;
-    const uint32_t po = ITEM_AT(IT_PO, idx), to = ITEM_AT(IT_TO, idx), q = ITEM_AT(IT_Q, idx);
-    const int mt = (int)ITEM_AT(IT_MT, idx), nt = (int)ITEM_AT(IT_NT, idx);
-    const int delta = (int)ITEM_AT(IT_DELTA, idx);
-    const int Tm = half ? MALCS_DIAG_HALF_T : T;
-    const int kmax = delta + (Tm - delta) / 2;
-    if (wave == 0) { out[0] = pairs[idx]; out[64] = m; out[128] = n; out[192] = (uint32_t)kmax | ((uint32_t)retry_class[idx] << 16); }
-    out += META_ROWS * 64;
-    // Word wd (all planes) of a stored sequence, zero beyond its end or in front of it.
-    struct word { uint32_t p[NP]; };
-    auto stored = [&](uint32_t base, int have, int wd) -> word {
-        word w;
-        const int valid = have - 32 * wd;
-        if (wd < 0 || valid <= 0) {
-#pragma unroll
-            for (int p = 0; p < NP; p++) w.p[p] = 0u;
-            return w;
-        }
-        const uint32_t keep = valid >= 32 ? ~0u : ((1u << valid) - 1u);
-        const uint32_t *src = planes + base + (uint32_t)wd * NP;
-        if constexpr (NP == 2) { const uint2 v = *reinterpret_cast<const uint2 *>(src); w.p[0] = v.x & keep; w.p[1] = v.y & keep; }
-        else if constexpr (NP == 4) { const uint4 v = *reinterpret_cast<const uint4 *>(src); w.p[0] = v.x & keep; w.p[1] = v.y & keep; w.p[2] = v.z & keep; w.p[3] = v.w & keep; }
-        else {
-#pragma unroll
-            for (int p = 0; p < NP; p++) w.p[p] = src[p] & keep;
-        }
-        return w;
-    };
-    // Each wave writes a contiguous quarter of the piece's rows: a row needs the 32 symbols from some position `at` of the
-    // stored pattern (rows) / text (columns), i.e. words at >> 5 and the next one, and the next row needs the next words
-    // (the previous ones when the piece runs backwards).
-    //   forward:  pattern rows from 32 j - kmax for row j of the piece (j counts the start limbs too), text block it
-    //   backward: pattern rows from m - 32 - (32 j - kmax), bit-reversed; text block n / 32 - 1 - it, bit-reversed
-    // Eight rows at a time, all nine words a stream needs for them asked for together instead of a dependent pair of
-    // loads per row.  (The kernel fetches 390 MB per C2 batch for 50 MB of planes, FETCH_SIZE, 69 us: a lane reads 8 bytes
-    // of a 128-byte line at a time and almost every such read goes to memory; asking together did not change that, one
-    // record per pair instead of a table per field took 35 MB off.  Open: loads that are coalesced across the lanes.)
-    const uint32_t n_waves = blockDim.x >> 6;
-    const uint32_t per = (n_rows + n_waves - 1u) / n_waves, r0 = wave * per, r1 = min(n_rows, r0 + per);
-    if (r0 >= r1) return;
-    // pattern: position of row j's first symbol in the stored sequence
-    auto pat_at = [&](int j) -> int { return (back ? (int)m - 32 - (32 * j - kmax) : 32 * j - kmax) + (int)q; };
-    const uint32_t psh = (uint32_t)pat_at((int)r0) & 31u;             // the same for every row: rows are 32 apart
-    auto limb_of = [&](const word &lo, const word &hi, uint32_t (&limb)[NP]) {
-#pragma unroll
-        for (int p = 0; p < NP; p++) {
-            const uint32_t v = psh ? ((lo.p[p] >> psh) | (hi.p[p] << (32u - psh))) : lo.p[p];
-            limb[p] = back ? __brev(v) : v;
-        }
-    };
-    // the limbs the window starts with: no text
-    const uint32_t start_rows = (uint32_t)(nlw - 1);
-    for (uint32_t r = r0; r < min(r1, start_rows); r++) {
-        const int pw = pat_at((int)r) >> 5;                          // arithmetic shift = floor
-        uint32_t limb[NP];
-        limb_of(stored(po, mt, pw), stored(po, mt, pw + 1), limb);
-#pragma unroll
-        for (int p = 0; p < NP; p++) out[(r * NP + p) * 64u] = limb[p];
-    }
-    // text: block `it` of the piece = stored words tb, tb + 1 shifted by q
-    auto txt_blk = [&](int it) -> int { return back ? (int)(n >> 5) - 1 - it : it; };
-    for (uint32_t rc = max(r0, start_rows); rc < r1; rc += 8u) {
-        const int nr = (int)min(8u, r1 - rc);                         // rows of this stretch (the same for every lane)
-        // row j of the stretch: pattern words pw + j, pw + j + 1 forwards (kept at 0 ... 8), pw - j, pw - j + 1 backwards
-        // (kept at 7 - j, 8 - j: the stretch's words start at pw - 7); the text likewise
-        const int pw = pat_at((int)rc) >> 5, tw = txt_blk((int)(rc - start_rows));
-        const int plow = back ? pw - 7 : pw, tlow = back ? tw - 7 : tw;
-        word pc[9], tc[9];
-#pragma unroll
-        for (int k = 0; k < 9; k++) {
-            const bool wanted = back ? k >= 8 - nr : k <= nr;
-            if (wanted) { pc[k] = stored(po, mt, plow + k); tc[k] = stored(to, nt, tlow + k); }
-            else {
-#pragma unroll
-                for (int p = 0; p < NP; p++) { pc[k].p[p] = 0u; tc[k].p[p] = 0u; }
-            }
-        }
-#pragma unroll
-        for (int j = 0; j < 8; j++) {
-            if (j >= nr) break;
-            const word &plo = back ? pc[7 - j] : pc[j], &phi = back ? pc[8 - j] : pc[j + 1];
-            const word &tlo = back ? tc[7 - j] : tc[j], &thi = back ? tc[8 - j] : tc[j + 1];
-            uint32_t limb[NP];
-            limb_of(plo, phi, limb);
-            const uint32_t it = rc + (uint32_t)j - start_rows;
-            uint32_t *o = out + (size_t)start_rows * NP * 64u + (size_t)it * 2u * NP * 64u;
-            uint32_t txt[NP];
-#pragma unroll
-            for (int p = 0; p < NP; p++) {
-                const uint32_t v = q ? ((tlo.p[p] >> q) | (thi.p[p] << (32u - q))) : tlo.p[p];
-                o[p * 64u] = limb[p];
-                txt[p] = back ? __brev(v) : v;
-            }
-            if constexpr (NP == 2) {
-                if (info & PIECE_CODES) {              // symbols of columns 0-15 / 16-31, two bits each (plane 0 = low bit)
-                    auto spread = [](uint32_t x) -> uint32_t {
-                        x &= 0xffffu;
-                        x = (x | (x << 8)) & 0x00ff00ffu; x = (x | (x << 4)) & 0x0f0f0f0fu;
-                        x = (x | (x << 2)) & 0x33333333u; x = (x | (x << 1)) & 0x55555555u;
-                        return x;
-                    };
-                    const uint32_t c0 = spread(txt[0]) | (spread(txt[1]) << 1);
-                    const uint32_t c1 = spread(txt[0] >> 16) | (spread(txt[1] >> 16) << 1);
-                    txt[0] = c0; txt[1] = c1;
-                }
-            }
-#pragma unroll
-            for (int p = 0; p < NP; p++) o[(NP + p) * 64u] = txt[p];
-        }
-    }
-}
-
-__global__ void __launch_bounds__(256)
-k_plan_gather(const int32_t *__restrict__ dist, const uint32_t *__restrict__ list, uint32_t n, int32_t *__restrict__ out)
-{
-    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i < n) out[i] = dist[list[i]];
-}
+#include "malcs_plan.inc"
 
 // ---- one block of 32 columns, skewed inside the lane ---------------------------------------------
 // A wave issues in order, and the straightforward order (limb after limb, column after column) makes
@@ -776,6 +509,7 @@ k_llcs_diag(const uint32_t *__restrict__ rows, const uint32_t *__restrict__ piec
         asm volatile("s_load_dword %0, %3, %6\n\ts_load_dword %1, %4, %6\n\ts_load_dword %2, %5, %6\n\ts_waitcnt lgkmcnt(0)"
                      : "=&s"(off_s), "=&s"(info), "=&s"(jt) : "s"(piece_off), "s"(piece_info), "s"(piece_join), "s"(t4));
     }
+    if (!info) return;                                 // the grid is an upper bound of the plan's pieces (decided on the device)
     // the tile's slots in the join buffer (one 64-bit word per lane); for a piece that is not joined: the first tile's, unused
     const unsigned long long *const join_slots = reinterpret_cast<const unsigned long long *>(join_buf) + (size_t)((info & PIECE_JOINED) ? jt : 0u) * 64u;
     const uint32_t *rows_u = rows + (size_t)off_s * 64u;                                               // the piece's rows
@@ -973,7 +707,9 @@ k_llcs_diag(const uint32_t *__restrict__ rows, const uint32_t *__restrict__ piec
             __builtin_nontemporal_store(d, &dist[pid]);
         } else {
             const uint32_t cls = kc >> 16;
-            if (stamps == reinterpret_cast<unsigned long long *>(1)) return;      // dev (MALCS_DIAG_NORETRY): timing experiments with wrong results
+#ifdef MALCS_DEV
+            if (stamps == reinterpret_cast<unsigned long long *>(1)) return;      // dev build only (MALCS_DIAG_NORETRY): timing experiments with wrong results
+#endif
             const uint32_t idx = atomicAdd(&retry_count[cls], 1u);
             if (idx < retry_cap[cls]) retry_list[retry_first[cls] + idx] = pid;
         }
@@ -1006,19 +742,26 @@ void malcs_diag_release(malcs_batch *b)
     d = diag_plan();
 }
 
-// Everything the plan of a batch's window class needs, in the order it happens:
-//   1. (device) k_plan_ends: common ends, what is left of every pair, histogram of block counts;
-//      a sample of the pairs goes through the full-matrix kernel, whose distances decide the mode of the class;
-//   2. one copy back (histogram + sample), the plan's only synchronisation;
-//   3. (host, from the histogram alone) tiles of 64 pairs of equal length, their mode, their pieces: which tiles are
-//      cut and where, which piece runs as which workgroup, where its rows start;
-//   4. (device) k_plan_scatter puts the pairs into their slots, k_diag_layout writes the rows.
-// Nothing after step 2 waits: the launch that follows is ordered behind the plan by the stream.
-static int plan_window(malcs_batch *b, int nlw, const std::vector<uint32_t> &pairs, const std::vector<uint8_t> &retry_class,
-                       const std::vector<diag_retry> &classes)
+// Everything the window class of a batch needs before it can run, in two parts.
+//
+// malcs_diag_setup, once per batch, from the LENGTHS of its pairs alone (which malcs_batch_create is given): the pairs of
+// the class and their retry classes in device memory, one allocation for everything a plan writes (sized by upper
+// bounds: the row buffer holds the blocks of the untrimmed texts, which the trimmed ones cannot exceed), the sub-pairs of
+// the sample.
+//
+// malcs_diag_plan, per plan, everything that depends on what the sequences HOLD, queued on the context's stream with
+// nothing coming back to the host:
+//   1. k_plan_ends: common ends, what is left of every pair, histogram of block counts; in the same launch the
+//      sample: about a thousand pairs, each cut in the middle, through the full-matrix wave;
+//   2. k_plan_scatter puts the pairs into their slots (counting sort);
+//   3. k_diag_layout writes the rows of every piece; its first workgroup deals the pieces to the SIMDs: the table of the launch.
+// (malcs_plan.inc has the kernels and why there are three launches and no more.)
+// The launch that follows is ordered behind the plan by the stream.
+int malcs_diag_setup(malcs_batch *b, int nlw, const std::vector<uint32_t> &pairs, const std::vector<uint8_t> &retry_class,
+                     const std::vector<diag_retry> &classes)
 {
+    malcs_diag_release(b);
     diag_plan &d = b->diag;
-    d = diag_plan();
     if (pairs.empty()) return MALCS_OK;
     if (b->n_planes > 4 || !(nlw == 2 || nlw == 3 || nlw == 4 || nlw == 5 || nlw == 8)) {
         malcs_set_error("no window kernel for %d limbs and %d bit planes", nlw, b->n_planes);
@@ -1026,270 +769,58 @@ static int plan_window(malcs_batch *b, int nlw, const std::vector<uint32_t> &pai
     }
     malcs_ctx *ctx = b->ctx;
     hipStream_t st = ctx->stream;
-    const int T = malcs_diag_threshold(nlw);
-    malcs_stage_trace trace("window plan");
     const uint32_t count = (uint32_t)pairs.size();
     const uint32_t NP = (uint32_t)b->n_planes;
-    // MALCS_DIAG_TRIM=0 keeps the common ends inside the window
-    const int trim = !(getenv("MALCS_DIAG_TRIM") && atoi(getenv("MALCS_DIAG_TRIM")) == 0);
-    const uint32_t min_rows = 32u * (2u * (uint32_t)nlw + 2u);
     // (every pair here passed malcs_dist_plan's test: length difference <= T, at least 2 nlw + 2 blocks; it also noted the
-    // longest sequence among them -- one more pass over 100 000 pairs cost 0.05 ms here)
+    // longest sequence among them and the blocks of their texts)
     const uint32_t max_len = b->plan_window_longest;
     if (!max_len) { malcs_set_error("window plan: empty sequences"); return MALCS_ERR_INTERNAL; }
     const uint32_t HB = (max_len + 31u) / 32u + 2u;          // histogram bins per group: block counts 0 ... HB - 1
-
-    // ---- 1. device: ends, items, histogram; the sample -------------------------------------------------
-    const bool can_half = nlw == 3 && NP == 2 && !getenv("MALCS_DIAG_GENERIC");
-    bool half_mode = false, sampled = false;
-    std::vector<uint32_t> sample;
-    if (can_half) {
-        const char *env = getenv("MALCS_DIAG_HALF");
-        if (env && *env) half_mode = atoi(env) != 0;
-        else if (count >= 4096) {
-            // two limbs (T = 48, a quarter less work) when no distance of a sample of about a thousand pairs comes near
-            // the threshold: whatever exceeds it is redone over the full matrix, at ten times the cost of a window
-            sampled = true;
-            const size_t stride = count / 1024;
-            for (size_t i = stride / 2; i < count; i += stride) sample.push_back((uint32_t)i);
-        }
-    }
-    size_t temp_dw = 0;
-    auto carve = [](size_t &total, size_t dwords) { const size_t at = total; total += (dwords + 63) & ~(size_t)63; return at; };
-    const size_t at_pairs = carve(temp_dw, count), at_cls = carve(temp_dw, (count + 3) / 4), at_item = carve(temp_dw, (size_t)ITEM_STRIDE * count);
-    const size_t at_hist = carve(temp_dw, 2 * (size_t)HB), at_slot = carve(temp_dw, (size_t)((count + 63) / 64) * 64);
-    const size_t at_sample = carve(temp_dw, 2 * sample.size() + 1), at_scount = carve(temp_dw, 64);
-    pool_scoped<uint32_t> temp(ctx);
-    MALCS_HIP(temp.alloc(temp_dw));
-    uint32_t *const d_pairs = temp.p + at_pairs, *const d_item = temp.p + at_item, *const d_hist = temp.p + at_hist;
-    uint32_t *const d_slot = temp.p + at_slot, *const d_sample = temp.p + at_sample, *const d_scount = temp.p + at_scount;
-    uint8_t *const d_cls = reinterpret_cast<uint8_t *>(temp.p + at_cls);
-    MALCS_HIP(malcs_h2d(st, d_pairs, pairs.data(), count * sizeof(uint32_t)));
-    MALCS_HIP(malcs_h2d(st, d_cls, retry_class.data(), count));
-    MALCS_HIP(hipMemsetAsync(d_hist, 0, 2 * (size_t)HB * sizeof(uint32_t), st));
-    const dim3 g256((count + 255u) / 256u), b256(256);
-    const size_t hist_lds = 2 * (size_t)HB * sizeof(uint32_t);
-    if (2 * hist_lds > 60000) { malcs_set_error("window plan: sequences of %u symbols are beyond its histogram", max_len); return MALCS_ERR_TOO_LONG; }
-    switch (NP) {
-    case 2: hipLaunchKernelGGL(k_plan_ends<2>, g256, b256, hist_lds, st, b->d_planes, b->d_a_off, b->d_a_len, b->d_b_off, b->d_b_len, d_pairs, count, min_rows, trim, HB, d_item, d_hist); break;
-    case 3: hipLaunchKernelGGL(k_plan_ends<3>, g256, b256, hist_lds, st, b->d_planes, b->d_a_off, b->d_a_len, b->d_b_off, b->d_b_len, d_pairs, count, min_rows, trim, HB, d_item, d_hist); break;
-    case 4: hipLaunchKernelGGL(k_plan_ends<4>, g256, b256, hist_lds, st, b->d_planes, b->d_a_off, b->d_a_len, b->d_b_off, b->d_b_len, d_pairs, count, min_rows, trim, HB, d_item, d_hist); break;
-    }
-    MALCS_HIP(hipGetLastError());
-    std::vector<int32_t> sample_dist(sample.size(), 0);
-    if (sampled) {
-        // the sampled pairs through k_llcs_bitpar_list (exact distances into d_dist, where the real launch overwrites
-        // them later), all in ONE class: the fewest words per lane that 64 lanes per pair allow for the longest of
-        // them -- the sample is a few dozen waves, so its time is the time of one wave, and that is columns x limbs
-        uint32_t longest = 0;
-        std::vector<uint32_t> list(sample.size());
-        for (size_t k = 0; k < sample.size(); k++) { list[k] = pairs[sample[k]]; longest = std::max(longest, std::min(b->a_len[list[k]], b->b_len[list[k]])); }
-        const uint32_t words = std::max(1u, (longest + 63u) / 64u);
-        int W = 1, L = 1;
-        while ((uint32_t)W * 64u < words) W *= 2;
-        while ((uint32_t)(W * L) < words) L *= 2;
-        const uint32_t n_sample = (uint32_t)list.size(), ppw = 64u / (uint32_t)L;
-        MALCS_HIP(malcs_h2d(st, d_sample, list.data(), list.size() * sizeof(uint32_t)));
-        MALCS_HIP(malcs_h2d(st, d_scount, &n_sample, sizeof(uint32_t)));
-        const int rc = malcs_dist_launch_list(st, b->n_planes, W, L, b->d_planes, b->d_a_off, b->d_a_len, b->d_b_off, b->d_b_len,
-                                              d_sample, 0, d_scount, n_sample, (n_sample + ppw - 1u) / ppw, b->d_dist);
-        if (rc) return rc;
-        hipLaunchKernelGGL(k_plan_gather, dim3(((uint32_t)list.size() + 255u) / 256u), b256, 0, st, b->d_dist, d_sample, (uint32_t)list.size(),
-                           reinterpret_cast<int32_t *>(d_sample + list.size()));
-        MALCS_HIP(hipGetLastError());
-        MALCS_HIP(malcs_d2h(st, sample_dist.data(), d_sample + list.size(), list.size() * sizeof(int32_t)));
-    }
-    // ---- 2. the one copy back ----------------------------------------------------------------------------
-    std::vector<uint32_t> hist(2 * (size_t)HB);
-    MALCS_HIP(malcs_d2h(st, hist.data(), d_hist, hist.size() * sizeof(uint32_t)));
-    MALCS_HIP(malcs_sync(st));
-    trace.lap("ends, histogram, sample (device) + copy back");
-    if (sampled) {
-        int32_t worst = 0;
-        for (int32_t x : sample_dist) worst = std::max(worst, x);
-        half_mode = worst <= MALCS_DIAG_HALF_T - 6;
-    }
-
-    // ---- 3. host: tiles and pieces from the histogram ----------------------------------------------------
-    // Sorted order of the slots: by blocks, ascending; in two-limb mode the pairs whose length difference that mode
-    // cannot hold come last, as a group of their own (their tiles run with three limbs).  `start` is the exclusive scan
-    // of the histogram in that order = the cursors of the scatter kernel.
-    std::vector<uint32_t> start(2 * (size_t)HB);
-    std::vector<uint32_t> key_order;                           // keys with pairs, in sorted order
-    {
-        uint32_t acc = 0;
-        auto take = [&](uint32_t key) { start[key] = acc; if (hist[key]) key_order.push_back(key); acc += hist[key]; };
-        if (half_mode) { for (uint32_t g = 0; g < 2; g++) for (uint32_t it = 0; it < HB; it++) take(g * HB + it); }
-        else           { for (uint32_t it = 0; it < HB; it++) for (uint32_t g = 0; g < 2; g++) take(g * HB + it); }
-        if (acc != count) { malcs_set_error("window plan: histogram holds %u of %u pairs", acc, count); return MALCS_ERR_INTERNAL; }
-    }
+    if (2u * HB > DEAL_HB2) { malcs_set_error("window plan: sequences of %u symbols are beyond its histogram", max_len); return MALCS_ERR_TOO_LONG; }
     const uint32_t n_tiles = (count + 63u) / 64u;
-    std::vector<uint32_t> tile_iters(n_tiles);                 // blocks of the tile's longest pair | half << 31
-    uint64_t cells = 0;
-    uint32_t n_half = 0;
-    {
-        size_t k = 0;                                          // walks key_order
-        uint32_t used = 0;                                     // pairs of key_order[k] already placed
-        for (uint32_t t = 0; t < n_tiles; t++) {
-            const uint32_t want = std::min(64u, count - t * 64u);
-            uint32_t have = 0, longest = 1;
-            bool half = half_mode;
-            while (have < want) {
-                const uint32_t key = key_order[k], avail = hist[key] - used, take = std::min(avail, want - have);
-                longest = std::max(longest, key % HB);
-                half = half && key < HB;
-                have += take; used += take;
-                if (used == hist[key]) { k++; used = 0; }
-            }
-            tile_iters[t] = longest | (half ? 0x80000000u : 0u);
-            n_half += half;
-            cells += (uint64_t)(half ? 64 : 32 * nlw) * 32u * longest * want;
+    const uint32_t S = (uint32_t)std::max(1, ctx->prop.multiProcessorCount) * 4u;
+    const bool can_half = nlw == 3 && NP == 2 && !getenv("MALCS_DIAG_GENERIC");
+    int cut_mode = -1;                                       // MALCS_DIAG_CUT=0 / 1: never / always
+    if (const char *env = getenv("MALCS_DIAG_CUT")) if (*env) cut_mode = atoi(env) != 0;
+    const bool cut_possible = can_half && (cut_mode > 0 || (cut_mode < 0 && 2u * n_tiles <= 4u * S));
+    const uint32_t n_launch = cut_possible ? 2u * n_tiles : n_tiles;
+
+    // the sample: pairs at equal distances through the class, each as two sub-pairs (cut at the block nearest the
+    // middle of either sequence); all sub-pairs in ONE full-matrix class, the narrowest their longest allows -- the
+    // sample is a few hundred waves that run side by side, so its time is the time of one wave: columns x limbs
+    std::vector<uint32_t> sample;                            // arrays of 2 n_sample entries: a_off, a_len, b_off, b_len, list; n_sample: correction
+    uint32_t n_sample = 0;
+    int sW = 1, sL = 1;
+    const char *env_half = getenv("MALCS_DIAG_HALF");
+    const bool forced = env_half && *env_half;
+    if (can_half && !forced && count >= 4096) {
+        const size_t stride = count / 1024;
+        n_sample = (uint32_t)((count - stride / 2 + stride - 1) / stride);
+        sample.resize((size_t)11 * n_sample);
+        uint32_t *sa_off = sample.data(), *sa_len = sa_off + 2 * (size_t)n_sample, *sb_off = sa_len + 2 * (size_t)n_sample,
+                 *sb_len = sb_off + 2 * (size_t)n_sample, *list = sb_len + 2 * (size_t)n_sample, *corr = list + 2 * (size_t)n_sample;
+        uint32_t longest = 0, k = 0;
+        for (size_t i = stride / 2; i < count && k < n_sample; i += stride, k++) {
+            const uint32_t pid = pairs[i];
+            const uint32_t la = b->a_len[pid], lb = b->b_len[pid];
+            // The second parts start at block boundaries of the arena: a is cut at the boundary nearest its middle, b at
+            // the boundary nearest the same fraction of its length.  That is up to 16 symbols off, which either part
+            // pays for with as many insertions or deletions: known here, taken off again by the deal kernel.
+            const uint32_t ra = 32u * ((la / 32u + 1u) / 2u);
+            const uint32_t ideal = (uint32_t)((uint64_t)ra * lb / std::max(la, 1u));
+            const uint32_t rb = std::min(32u * ((ideal + 16u) / 32u), 32u * (lb / 32u));
+            corr[k] = 2u * (rb > ideal ? rb - ideal : ideal - rb);
+            sa_off[2 * k] = b->a_off[pid]; sa_len[2 * k] = ra; sb_off[2 * k] = b->b_off[pid]; sb_len[2 * k] = rb;
+            sa_off[2 * k + 1] = b->a_off[pid] + (ra / 32u) * NP; sa_len[2 * k + 1] = la - ra;
+            sb_off[2 * k + 1] = b->b_off[pid] + (rb / 32u) * NP; sb_len[2 * k + 1] = lb - rb;
+            list[2 * k] = 2 * k; list[2 * k + 1] = 2 * k + 1;
+            longest = std::max(longest, std::max(std::min(ra, rb), std::min(la - ra, lb - rb)));
         }
+        n_sample = k;
+        const uint32_t words = std::max(1u, (longest + 63u) / 64u);
+        while ((uint32_t)sW * 64u < words) sW *= 2;
+        while ((uint32_t)(sW * sL) < words) sL *= 2;
     }
-    // Pieces.  All workgroups of a launch are resident at once and the dispatcher deals them round-robin: workgroups w
-    // and w' share a SIMD iff w = w' (mod #SIMDs) (tools/wave_placement.hip, up to four waves per SIMD).  A launch ends
-    // with its most loaded SIMD, and a wave alone on a SIMD issues at two thirds of the rate two or three waves reach
-    // together (5.3 against 3.4 / 3.2 clk per instruction), so what a SIMD holds should be equally long and run side by
-    // side.  A tile in two-limb mode can be cut once, anywhere (see the kernel): every such tile is cut in the middle,
-    // which doubles the waves of a launch, and the pieces are dealt longest first to the SIMD with the least work so far
-    // among those with a free slot, SIMDs with fewer slots first -- at C2 (1 563 tiles, 3 126 pieces, 1 024 SIMDs) the 970
-    // SIMDs with three waves get the halves of the longest tiles, the 54 with four the halves of the shortest.  (Laying
-    // the tiles end to end and cutting the line into one stretch per SIMD balances the blocks exactly, but leaves
-    // a SIMD with pieces of different length, the longest of which ends up running alone: 37.4 against 34.2 us uncut.)
-    // Beyond four pieces per SIMD the hardware cannot hold all waves at once and balances by itself: no cuts then.
-    // MALCS_DIAG_CUT=0 / 1: never / always.
-    struct piece { uint32_t tile, blocks, flags, join; };
-    const uint32_t S = std::max(1, ctx->prop.multiProcessorCount) * 4u;
-    bool cut = n_half > 0 && 2u * n_tiles <= 4u * S;
-    if (const char *env = getenv("MALCS_DIAG_CUT")) if (*env) cut = n_half > 0 && atoi(env) != 0;
-    std::vector<piece> pieces;
-    uint32_t n_joins = 0;
-    // MALCS_DIAG_LDS=0: two-limb pieces fold the match masks from the planes (diag_halves_dna) instead of reading them from LDS
-    const bool lds = NP == 2 && !(getenv("MALCS_DIAG_LDS") && atoi(getenv("MALCS_DIAG_LDS")) == 0);
-    const uint32_t half_flags = PIECE_HALF | (lds ? PIECE_CODES : 0u);
-    {
-        // cost in sixteenths of a three-limb block; a block in two-limb mode costs 0.74
-        auto cost = [](const piece &x) -> uint32_t { return x.blocks * ((x.flags & PIECE_HALF) ? 12u : 16u); };
-        // Deals `todo` to the SIMDs [lo, hi) of a launch of n workgroups (SIMD i holds workgroups i, i + S, ...), most
-        // expensive first, each to the least loaded SIMD with a free slot (ties: fewest slots, then lowest number);
-        // returns the largest load.  Heap of packed keys: load << 32 | slots << 16 | SIMD.
-        auto deal = [&](std::vector<piece> &todo, uint32_t lo, uint32_t hi, uint32_t n, std::vector<piece> &out) -> uint64_t {
-            std::vector<uint64_t> heap;
-            std::vector<uint32_t> used;
-            std::stable_sort(todo.begin(), todo.end(), [&](const piece &x, const piece &y) { return cost(x) > cost(y); });
-            heap.clear();
-            used.assign(S, 0u);
-            for (uint32_t i = lo; i < std::min(hi, n); i++) heap.push_back((uint64_t)std::min((n - i + S - 1) / S, 0xffffu) << 16 | i);
-            std::make_heap(heap.begin(), heap.end(), std::greater<uint64_t>());
-            uint64_t worst = 0;
-            for (const piece &x : todo) {
-                if (heap.empty()) return ~0ull;                // more pieces than slots: not a plan
-                std::pop_heap(heap.begin(), heap.end(), std::greater<uint64_t>());
-                uint64_t &top = heap.back();
-                const uint32_t idx = (uint32_t)top & 0xffffu, slots = (n - idx + S - 1) / S;
-                out[idx + used[idx] * S] = x;
-                top += (uint64_t)cost(x) << 32;
-                worst = std::max(worst, top >> 32);
-                if (++used[idx] == slots) heap.pop_back(); else std::push_heap(heap.begin(), heap.end(), std::greater<uint64_t>());
-            }
-            return worst;
-        };
-        auto middle = [](uint32_t it) { return std::min(it - 2u, std::max(2u, (it + 1u) / 2u)); };
-        std::vector<piece> todo;                               // the tiles are sorted by length, shortest first
-        todo.reserve(2 * (size_t)n_tiles);
-        bool uniform = true;                                   // every tile is cut
-        uint64_t total = 0;
-        for (uint32_t t = 0; t < n_tiles; t++) {
-            const uint32_t it = tile_iters[t] & 0x7fffffffu;
-            const bool half = tile_iters[t] >> 31;
-            total += it;
-            if (cut && half && it >= 4 && it <= 2040) {    // the join word holds the ones of at most 2 046 blocks
-                const uint32_t c = middle(it);
-                todo.push_back({t, c, half_flags | PIECE_JOINED, n_joins});
-                todo.push_back({t, it - c, half_flags | PIECE_JOINED | PIECE_BACK, n_joins});
-                n_joins++;
-            } else {
-                todo.push_back({t, it, half ? half_flags : 0u, 0u});
-                uniform = false;
-            }
-        }
-        const uint32_t n = (uint32_t)todo.size();
-        pieces.resize(n);
-        bool dealt = false;
-        // When n is not a multiple of S, r = n mod S SIMDs hold one piece more than the others, and with every tile cut in
-        // the middle those SIMDs hold (q + 1) / q of the others' work: the launch waits for them (C2: 54 of 1 024 SIMDs
-        // with four pieces of 13 blocks next to three of 15, 28.6 us for 100 000 pairs against 26.5 for 98 304).  A cut
-        // may be anywhere, so the pieces of the smaller group of SIMDs are made as long as that group's share of all
-        // blocks asks for: they come from as many tiles (the shortest when the group holds more pieces per SIMD, else
-        // the longest), whose other parts join the larger group's pieces; either group is dealt on its own.
-        // Kept when its most loaded SIMD is below the plain plan's, and only from two pieces per SIMD on: below that a
-        // SIMD's time is not its blocks (one wave alone issues at two thirds of the rate of two), and two short pieces
-        // side by side beat a long one alone (50 000 pairs: 18.3 us with middle cuts, 21.3 balanced).
-        // MALCS_DIAG_BALANCE=0: middle cuts only.
-        const uint32_t q = n / S, r = n % S;
-        if (uniform && q >= 2 && r != 0 && !(getenv("MALCS_DIAG_BALANCE") && atoi(getenv("MALCS_DIAG_BALANCE")) == 0)) {
-            const uint64_t na = (uint64_t)r * (q + 1), nb = (uint64_t)(S - r) * q;      // pieces on the fuller / the other SIMDs
-            const bool minor_a = na <= nb;
-            const uint32_t n_ab = (uint32_t)std::min(na, nb);                          // <= n_tiles: na + nb = 2 n_tiles
-            const uint64_t share = (uint64_t)(minor_a ? r : S - r) * total / S;
-            const uint32_t base = (uint32_t)(share / n_ab), extra = (uint32_t)(share % n_ab);
-            std::vector<piece> minor, major;
-            minor.reserve(n_ab); major.reserve(n);
-            for (uint32_t t = 0; t < n_tiles; t++) {
-                const uint32_t it = tile_iters[t] & 0x7fffffffu;
-                const bool ab = minor_a ? t < n_ab : t >= n_tiles - n_ab;
-                if (ab) {
-                    const uint32_t k = minor_a ? t : t - (n_tiles - n_ab);
-                    const uint32_t c = std::min(it - 2u, std::max(2u, base + (k < extra ? 1u : 0u)));
-                    minor.push_back({t, c, half_flags | PIECE_JOINED, t});
-                    major.push_back({t, it - c, half_flags | PIECE_JOINED | PIECE_BACK, t});
-                } else {
-                    const uint32_t c = middle(it);
-                    major.push_back({t, c, half_flags | PIECE_JOINED, t});
-                    major.push_back({t, it - c, half_flags | PIECE_JOINED | PIECE_BACK, t});
-                }
-            }
-            std::vector<piece> alt(n);
-            uint64_t w0 = 0, w1 = 0, w_plain = ~0ull;
-            const bool side_by_side = count >= 16384;              // the three deals at once, on the context's threads
-            if (side_by_side) {
-                pieces.assign(n, piece{});
-                malcs_ctx_workers(ctx)->run(3, [&](int k) {
-                    if (k == 0) w1 = deal(major, minor_a ? r : 0u, minor_a ? S : r, n, alt);
-                    else if (k == 1) w0 = deal(minor, minor_a ? 0u : r, minor_a ? r : S, n, alt);
-                    else w_plain = deal(todo, 0, S, n, pieces);
-                });
-            } else {
-                w0 = deal(minor, minor_a ? 0u : r, minor_a ? r : S, n, alt);
-                w1 = deal(major, minor_a ? r : 0u, minor_a ? S : r, n, alt);
-            }
-            // what the plain plan cannot beat: its fuller SIMDs hold q + 1 pieces, at best the smallest ones
-            std::vector<uint32_t> small;
-            for (uint32_t t = 0; t < std::min(n_tiles, q + 1u); t++) {
-                const uint32_t it = tile_iters[t] & 0x7fffffffu, c = middle(it);
-                small.push_back(c); small.push_back(it - c);
-            }
-            std::sort(small.begin(), small.end());
-            uint64_t bound = 0;
-            for (uint32_t k = 0; k <= q; k++) bound += small[k] * 12u;
-            if (std::max(w0, w1) <= bound || std::max(w0, w1) < (side_by_side ? w_plain : deal(todo, 0, S, n, pieces))) pieces.swap(alt);
-            dealt = true;
-        }
-        if (!dealt) deal(todo, 0, S, n, pieces);
-    }
-    const uint32_t n_pieces = (uint32_t)pieces.size();
-    std::vector<uint32_t> piece_tab((size_t)4 * n_pieces + 1);      // off[n_pieces + 1], info, tile, join
-    uint64_t row = 0;
-    for (uint32_t i = 0; i < n_pieces; i++) {
-        piece_tab[i] = (uint32_t)row;
-        piece_tab[n_pieces + 1 + i] = pieces[i].blocks | pieces[i].flags;
-        piece_tab[2 * (size_t)n_pieces + 1 + i] = pieces[i].tile;
-        piece_tab[3 * (size_t)n_pieces + 1 + i] = pieces[i].join;
-        row += (uint64_t)META_ROWS + (uint64_t)(nlw - 1) * NP + (uint64_t)pieces[i].blocks * 2u * NP;
-        if (row >= 0xffffffffull) { malcs_set_error("window class too large; split the batch"); return MALCS_ERR_TOO_LONG; }
-    }
-    piece_tab[n_pieces] = (uint32_t)row;
-    trace.lap("tiles, pieces (host)");
 
     // retry bookkeeping: one list segment per full-matrix class, sized for the worst case
     d.retry = classes;
@@ -1297,54 +828,139 @@ static int plan_window(malcs_batch *b, int nlw, const std::vector<uint32_t> &pai
     for (uint32_t i = 0; i < count; i++) cap[retry_class[i]]++;
     uint32_t acc = 0;
     for (size_t c = 0; c < classes.size(); c++) { first[c] = acc; acc += cap[c]; d.retry[c].first = first[c]; d.retry[c].cap = cap[c]; }
-
-    // ---- 4. device: slots, rows ----------------------------------------------------------------------------
     const size_t ncls = std::max<size_t>(classes.size(), 1);
+
+    // The row buffer.  Tiles are 64 consecutive slots of the order sorted by (trimmed) block count, a tile's pieces hold
+    // the blocks of its longest pair: over one sorted run that sums to at most (all blocks) / 64 + the longest, the
+    // two-limb mode has two runs and a tile across their border, and no trimmed text has more blocks than the text itself.
+    const uint64_t blocks_cap = (b->plan_window_blocks + (uint64_t)count) / 64u + 4u * (uint64_t)HB + 64u;   // (+ count: a text grows to whole blocks)
+    const uint64_t rows_cap = (uint64_t)n_launch * ((uint64_t)META_ROWS + (uint64_t)(nlw - 1) * NP) + blocks_cap * 2u * NP + 2u * NP;
+    if (rows_cap >= 0xffffffffull) { malcs_set_error("window class too large; split the batch"); return MALCS_ERR_TOO_LONG; }
+
     size_t keep = 0;
-    const size_t at_rows = carve(keep, ((size_t)row + 2u * NP) * 64u);     // + one block of padding: the kernel prefetches unconditionally
-    const size_t at_tab = carve(keep, piece_tab.size());
+    auto carve = [](size_t &total, size_t dwords) { const size_t at = total; total += (dwords + 63) & ~(size_t)63; return at; };
+    const uint32_t set_words = 4u * HB + 8u;                               // bins and cursors of both groups, two 64-bit column sums, two of the sample
+    const size_t at_rows = carve(keep, (size_t)rows_cap * 64u);            // (includes one block of padding: the kernel prefetches unconditionally)
+    const size_t at_pairs = carve(keep, count), at_cls = carve(keep, (count + 3) / 4), at_item = carve(keep, (size_t)ITEM_STRIDE * count);
+    const size_t at_sets = carve(keep, 2 * (size_t)set_words);
+    const size_t at_slot = carve(keep, (size_t)n_tiles * 64);
+    const size_t at_tab = carve(keep, (size_t)6 * n_launch + 4);
     const size_t at_list = carve(keep, std::max<uint32_t>(acc, 1)), at_first = carve(keep, ncls), at_cap = carve(keep, ncls);
     const size_t at_count = carve(keep, 2 * ncls);                         // two sets, used by alternate launches
-    const size_t at_jbuf = carve(keep, (size_t)std::max(n_joins, 1u) * 128u);   // one 64-bit word per lane of a cut tile
-    const size_t at_titers = carve(keep, n_tiles);
+    const size_t at_jbuf = carve(keep, (size_t)(cut_possible ? n_tiles : 1u) * 128u);   // one 64-bit word per lane of a cut tile
+    const size_t at_stats = carve(keep, PS_FIELDS);
+    const size_t at_sample = carve(keep, (size_t)11 * n_sample + 64), at_sdist = carve(keep, 2 * (size_t)n_sample + 64);
     MALCS_HIP(malcs_pool_alloc(ctx, (void **)&d.d_rows, keep * sizeof(uint32_t)));
     (void)at_rows;                                                         // the rows come first: d_rows is the allocation
-    uint32_t *const tab = d.d_rows + at_tab;
-    d.d_piece_off = tab; d.d_piece_info = tab + n_pieces + 1; d.d_piece_join = tab + 3 * (size_t)n_pieces + 1;
-    uint32_t *const d_piece_tile = tab + 2 * (size_t)n_pieces + 1, *const d_tile_iters = d.d_rows + at_titers;
-    d.d_retry_list = d.d_rows + at_list; d.d_retry_first = d.d_rows + at_first; d.d_retry_cap = d.d_rows + at_cap;
-    d.d_retry_count = d.d_rows + at_count; d.d_join_buf = d.d_rows + at_jbuf;
-    MALCS_HIP(malcs_h2d(st, tab, piece_tab.data(), piece_tab.size() * sizeof(uint32_t)));
-    MALCS_HIP(malcs_h2d(st, d_tile_iters, tile_iters.data(), n_tiles * sizeof(uint32_t)));
-    MALCS_HIP(malcs_h2d(st, d_hist, start.data(), start.size() * sizeof(uint32_t)));          // the histogram becomes the cursors
+    uint32_t *const base = d.d_rows;
+    d.d_pairs = base + at_pairs; d.d_cls = reinterpret_cast<uint8_t *>(base + at_cls); d.d_item = base + at_item;
+    d.d_sets = base + at_sets; d.set_words = set_words; d.d_slot = base + at_slot;
+    d.d_piece_off = base + at_tab; d.d_piece_info = d.d_piece_off + n_launch + 1; d.d_piece_join = d.d_piece_info + n_launch;
+    d.d_piece_place = d.d_piece_join + n_launch; d.d_lay_off = d.d_piece_place + n_launch; d.d_lay_info = d.d_lay_off + n_launch;
+    d.d_join_buf = base + at_jbuf; d.d_stats = base + at_stats;
+    d.d_retry_list = base + at_list; d.d_retry_first = base + at_first; d.d_retry_cap = base + at_cap; d.d_retry_count = base + at_count;
+    d.d_sample = base + at_sample; d.d_sample_dist = reinterpret_cast<int32_t *>(base + at_sdist);
+    // what starts at zero: the two sets of histogram, cursors and column sums (every plan zeroes the other set for the
+    // next), the join buffer (every launch leaves its slots at zero), the statistics
+    MALCS_HIP(hipMemsetAsync(d.d_sets, 0, 2 * (size_t)set_words * sizeof(uint32_t), st));
+    MALCS_HIP(hipMemsetAsync(d.d_join_buf, 0, (at_stats - at_jbuf + PS_FIELDS) * sizeof(uint32_t), st));
+    MALCS_HIP(malcs_h2d(st, d.d_pairs, pairs.data(), count * sizeof(uint32_t)));
+    MALCS_HIP(malcs_h2d(st, d.d_cls, retry_class.data(), count));
     if (!classes.empty()) {
         MALCS_HIP(malcs_h2d(st, d.d_retry_first, first.data(), classes.size() * sizeof(uint32_t)));
         MALCS_HIP(malcs_h2d(st, d.d_retry_cap, cap.data(), classes.size() * sizeof(uint32_t)));
     }
-    MALCS_HIP(hipMemsetAsync(d.d_retry_count, 0, 2 * ncls * sizeof(uint32_t), st));
-    MALCS_HIP(hipMemsetAsync(d.d_join_buf, 0, (size_t)std::max(n_joins, 1u) * 128u * sizeof(uint32_t), st));
-    MALCS_HIP(hipMemsetAsync(d_slot, 0xff, (size_t)n_tiles * 64u * sizeof(uint32_t), st));
-    hipLaunchKernelGGL(k_plan_scatter, dim3((count + 1023u) / 1024u), dim3(1024), 2 * hist_lds, st, d_item, count, HB, d_hist, d_slot);
-    const dim3 layout_block(256);      // four waves per piece; with two or one the kernel fetches twice as much and takes 112 / 128 us
-    switch (NP) {
-    case 2: hipLaunchKernelGGL(k_diag_layout<2>, dim3(n_pieces), layout_block, 0, st, b->d_planes, d_item, count, d_pairs, d_cls, d_slot, d_tile_iters, d.d_piece_off, d.d_piece_info, d_piece_tile, nlw, T, d.d_rows); break;
-    case 3: hipLaunchKernelGGL(k_diag_layout<3>, dim3(n_pieces), layout_block, 0, st, b->d_planes, d_item, count, d_pairs, d_cls, d_slot, d_tile_iters, d.d_piece_off, d.d_piece_info, d_piece_tile, nlw, T, d.d_rows); break;
-    case 4: hipLaunchKernelGGL(k_diag_layout<4>, dim3(n_pieces), layout_block, 0, st, b->d_planes, d_item, count, d_pairs, d_cls, d_slot, d_tile_iters, d.d_piece_off, d.d_piece_info, d_piece_tile, nlw, T, d.d_rows); break;
+    if (n_sample) {
+        MALCS_HIP(malcs_h2d(st, d.d_sample, sample.data(), sample.size() * sizeof(uint32_t)));
+        const uint32_t two = 2u * n_sample;
+        MALCS_HIP(malcs_h2d(st, d.d_sample + (size_t)11 * n_sample, &two, sizeof(uint32_t)));
     }
-    MALCS_HIP(hipGetLastError());
-    // copies of more than a megabyte do not go through the staging buffer: their sources (locals) must outlive them
-    if ((size_t)count * sizeof(uint32_t) > (1u << 20) || piece_tab.size() * sizeof(uint32_t) > (1u << 20)) MALCS_HIP(malcs_sync(st));
-    trace.lap("slots, rows (device, queued)");
-    d.nlw = nlw; d.T = T; d.n_tiles = n_tiles; d.n_pairs = count; d.window_cells = cells;
-    d.n_half_tiles = n_half; d.n_pieces = n_pieces; d.n_cut_tiles = n_joins;
-    if (d.n_half_tiles == n_tiles) d.T = MALCS_DIAG_HALF_T;    // what the plan reports: the threshold of every tile
+    MALCS_HIP(malcs_sync(st));                                             // the sources are locals (copies beyond the staging buffer read them directly)
+    d.nlw = nlw; d.T = malcs_diag_threshold(nlw); d.n_tiles = n_tiles; d.n_pairs = count; d.n_launch = n_launch;
+    d.max_len = max_len; d.HB = HB; d.can_half = can_half; d.cut_possible = cut_possible; d.n_sample = n_sample;
+    d.sample_W = sW; d.sample_L = sL; d.rows_cap = rows_cap; d.parity = 0; d.planned = false; d.plan_parity = 0;
+    d.sample_inside = n_sample && sW == 1 && sL > 1 && sL <= 32;                       // the sample as workgroups of the plan's first launch
     return MALCS_OK;
 }
 
-int malcs_diag_plan(malcs_batch *b, int nlw, const std::vector<uint32_t> &pairs, const std::vector<uint8_t> &retry_class,
-                    const std::vector<diag_retry> &classes)
+int malcs_diag_plan(malcs_batch *b)
 {
-    return plan_window(b, nlw, pairs, retry_class, classes);
+    diag_plan &d = b->diag;
+    if (!d.nlw) return MALCS_OK;
+    malcs_ctx *ctx = b->ctx;
+    hipStream_t st = ctx->stream;
+    const uint32_t count = d.n_pairs, NP = (uint32_t)b->n_planes, HB = d.HB, H2 = 2u * HB;
+    plan_args A;
+    A.planes = b->d_planes; A.a_off = b->d_a_off; A.a_len = b->d_a_len; A.b_off = b->d_b_off; A.b_len = b->d_b_len;
+    A.pairs = d.d_pairs; A.cls = d.d_cls; A.item = d.d_item; A.sets = d.d_sets; A.set_words = d.set_words;
+    d.plan_parity ^= 1u;
+    A.parity = d.plan_parity;
+    A.slot = d.d_slot; A.lay_off = d.d_lay_off; A.lay_info = d.d_lay_info; A.piece_off = d.d_piece_off; A.piece_info = d.d_piece_info;
+    A.piece_join = d.d_piece_join; A.piece_place = d.d_piece_place; A.retry_count = d.d_retry_count; A.stats = d.d_stats; A.rows = d.d_rows;
+    A.sample = d.d_sample; A.sample_dist = d.d_sample_dist;
+    A.HB = HB; A.count = count; A.n_tiles = d.n_tiles; A.n_launch = d.n_launch; A.S = (uint32_t)std::max(1, ctx->prop.multiProcessorCount) * 4u;
+    A.NP = NP; A.n_sample = d.n_sample; A.n_retry_words = 2u * (uint32_t)std::max<size_t>(d.retry.size(), 1);
+    A.min_rows = 32u * (2u * (uint32_t)d.nlw + 2u);
+    A.rows_cap = d.rows_cap; A.nlw = d.nlw; A.T = malcs_diag_threshold(d.nlw); A.can_half = d.can_half;
+    A.force_half = -1;
+    if (const char *env = getenv("MALCS_DIAG_HALF")) if (*env) A.force_half = atoi(env) != 0;
+    A.cut_mode = -1;
+    if (const char *env = getenv("MALCS_DIAG_CUT")) if (*env) A.cut_mode = atoi(env) != 0;
+    if (!d.cut_possible) A.cut_mode = 0;
+    A.cut_possible = d.cut_possible;
+    // MALCS_DIAG_LDS=0: two-limb pieces fold the match masks from the planes (diag_halves_dna) instead of reading them from LDS
+    A.lds_codes = NP == 2 && !(getenv("MALCS_DIAG_LDS") && atoi(getenv("MALCS_DIAG_LDS")) == 0);
+    A.balance = !(getenv("MALCS_DIAG_BALANCE") && atoi(getenv("MALCS_DIAG_BALANCE")) == 0);     // 0: middle cuts only
+    A.trim = !(getenv("MALCS_DIAG_TRIM") && atoi(getenv("MALCS_DIAG_TRIM")) == 0);              // 0 keeps the common ends inside the window
+    int logL = 0;
+    while ((1 << logL) < d.sample_L) logL++;
+    A.sample_logL = logL;
+    const uint32_t n2 = 2u * d.n_sample, ppw = 64u / (uint32_t)std::max(d.sample_L, 1);
+    A.sample_blocks = d.sample_inside ? ((n2 + ppw - 1u) / ppw + 3u) / 4u : 0u;
+    if (d.n_sample && !d.sample_inside) {
+        // sub-pairs beyond 4 096 rows (sequences beyond 8 kb): the sample as a launch of its own, in front of the plan
+        uint32_t *sa_off = d.d_sample, *sa_len = sa_off + n2, *sb_off = sa_len + n2, *sb_len = sb_off + n2, *list = sb_len + n2, *cnt = list + n2 + d.n_sample;
+        const int rc = malcs_dist_launch_list(st, b->n_planes, d.sample_W, d.sample_L, b->d_planes, sa_off, sa_len, sb_off, sb_len,
+                                              list, 0, cnt, n2, (n2 + ppw - 1u) / ppw, d.d_sample_dist);
+        if (rc) return rc;
+        hipLaunchKernelGGL(k_plan_sample_sums, dim3(1), dim3(256), 0, st, A);
+        MALCS_HIP(hipGetLastError());
+    }
+    const dim3 g_ends(A.sample_blocks + (count + 255u) / 256u), b256(256);
+    const size_t hist_lds = (size_t)H2 * sizeof(uint32_t);
+    switch (NP) {
+    case 2: if (d.sample_inside) hipLaunchKernelGGL((k_plan_ends<2, true>), g_ends, b256, hist_lds, st, A);
+            else hipLaunchKernelGGL((k_plan_ends<2, false>), g_ends, b256, hist_lds, st, A);
+            break;
+    case 3: hipLaunchKernelGGL((k_plan_ends<3, false>), g_ends, b256, hist_lds, st, A); break;
+    case 4: hipLaunchKernelGGL((k_plan_ends<4, false>), g_ends, b256, hist_lds, st, A); break;
+    }
+    MALCS_HIP(hipGetLastError());
+    hipLaunchKernelGGL(k_plan_scatter, dim3((count + 1023u) / 1024u), dim3(1024), 3 * hist_lds, st, A);
+    MALCS_HIP(hipGetLastError());
+    // the first workgroup deals the pieces to the SIMDs, the others write the rows of four places each
+    const dim3 g_layout(1u + (d.n_launch + 3u) / 4u);
+    const size_t layout_lds = ((size_t)std::max(2u * H2, RANK_BINS) + DEAL_MAX) * sizeof(uint32_t);
+    switch (NP) {
+    case 2: hipLaunchKernelGGL(k_diag_layout<2>, g_layout, dim3(1024), layout_lds, st, A); break;
+    case 3: hipLaunchKernelGGL(k_diag_layout<3>, g_layout, dim3(1024), layout_lds, st, A); break;
+    case 4: hipLaunchKernelGGL(k_diag_layout<4>, g_layout, dim3(1024), layout_lds, st, A); break;
+    }
+    MALCS_HIP(hipGetLastError());
+    d.parity = 0;                                                          // the deal has zeroed both sets of retry counters
+    d.planned = true;
+    return MALCS_OK;
+}
+
+int malcs_diag_stats(malcs_batch *b, uint32_t *stats)
+{
+    memset(stats, 0, PS_FIELDS * sizeof(uint32_t));
+    diag_plan &d = b->diag;
+    if (!d.nlw || !d.planned) return MALCS_OK;
+    MALCS_HIP(malcs_d2h(b->ctx->stream, stats, d.d_stats, PS_FIELDS * sizeof(uint32_t)));
+    MALCS_HIP(malcs_sync(b->ctx->stream));
+    if (stats[PS_ERROR]) { malcs_set_error("window plan failed on the device (code %u)", stats[PS_ERROR]); return MALCS_ERR_INTERNAL; }
+    return MALCS_OK;
 }
 
 // Launches the window kernel.  The retry counters exist twice: a launch appends through one set and zeroes
@@ -1368,18 +984,21 @@ int malcs_diag_launch(malcs_batch *b, bool advance, hipEvent_t start, hipEvent_t
     uint32_t *cur = d.d_retry_count + d.parity * ncls, *next = d.d_retry_count + (d.parity ^ 1u) * ncls;
     unsigned long long *stamps = nullptr;
     const char *stamp_path = getenv("MALCS_DIAG_STAMPS");          // dev: per-wave time stamps of this launch into a file
+#ifdef MALCS_DEV
     if (getenv("MALCS_DIAG_NORETRY")) stamps = reinterpret_cast<unsigned long long *>(1);
-    else if (stamp_path && *stamp_path) { MALCS_HIP(hipMalloc((void **)&stamps, (size_t)d.n_pieces * 48)); MALCS_HIP(hipMemsetAsync(stamps, 0, (size_t)d.n_pieces * 48, st)); }
+    else
+#endif
+    if (stamp_path && *stamp_path) { MALCS_HIP(hipMalloc((void **)&stamps, (size_t)d.n_launch * 48)); MALCS_HIP(hipMemsetAsync(stamps, 0, (size_t)d.n_launch * 48, st)); }
     if (start || stop)     // the dispatch's own time stamps (what a profiler reports as the kernel's duration)
-        hipExtLaunchKernelGGL(fn, dim3(d.n_pieces), dim3(64), 0, st, start, stop, 0, (const uint32_t *)d.d_rows, (const uint32_t *)d.d_piece_off,
+        hipExtLaunchKernelGGL(fn, dim3(d.n_launch), dim3(64), 0, st, start, stop, 0, (const uint32_t *)d.d_rows, (const uint32_t *)d.d_piece_off,
                               (const uint32_t *)d.d_piece_info, (const uint32_t *)d.d_piece_join, b->d_dist, d.d_retry_list,
                               (const uint32_t *)d.d_retry_first, (const uint32_t *)d.d_retry_cap, cur, next, advance ? ncls : 0u, d.d_join_buf, stamps);
     else
-        hipLaunchKernelGGL(fn, dim3(d.n_pieces), dim3(64), 0, st, d.d_rows, d.d_piece_off, d.d_piece_info, d.d_piece_join, b->d_dist,
+        hipLaunchKernelGGL(fn, dim3(d.n_launch), dim3(64), 0, st, d.d_rows, d.d_piece_off, d.d_piece_info, d.d_piece_join, b->d_dist,
                            d.d_retry_list, d.d_retry_first, d.d_retry_cap, cur, next, advance ? ncls : 0u, d.d_join_buf, stamps);
     MALCS_HIP(hipGetLastError());
     if (stamps > reinterpret_cast<unsigned long long *>(1)) {
-        std::vector<unsigned long long> host((size_t)d.n_pieces * 6);
+        std::vector<unsigned long long> host((size_t)d.n_launch * 6);
         MALCS_HIP(hipStreamSynchronize(st));
         MALCS_HIP(hipMemcpy(host.data(), stamps, host.size() * 8, hipMemcpyDeviceToHost));
         MALCS_HIP(hipFree(stamps));

@@ -158,19 +158,40 @@ struct diag_retry {        // pairs the window could not settle go back to their
 };
 struct diag_plan {
     int nlw = 0;                         // limbs in the window (0: no window class in this batch)
-    int T = 0;                           // results <= T are exact
-    uint32_t n_tiles = 0, n_pairs = 0, n_half_tiles = 0;   // n_half_tiles: tiles in two-limb mode (T = 48)
-    uint64_t window_cells = 0;           // sum over the class of 32 * nlw * (text length)
-    uint32_t n_pieces = 0, n_cut_tiles = 0;   // workgroups of a launch; tiles that run as two pieces (cut at a block boundary)
-    uint32_t *d_rows = nullptr;          // per piece, lane-interleaved rows of 64 dwords; the allocation the arrays below are parts of
-    uint32_t *d_piece_off = nullptr;     // first row of each piece
-    uint32_t *d_piece_info = nullptr;    // column blocks of each piece | mode flags
+    int T = 0;                           // results <= T are exact (the threshold of three-limb tiles)
+    uint32_t n_tiles = 0, n_pairs = 0;   // of the class (from the lengths alone)
+    uint32_t n_launch = 0;               // workgroups of a launch: an upper bound of the pieces (those beyond the plan's count leave at once)
+    uint32_t max_len = 0, HB = 0;        // longest sequence of the class; bins per group of the block-count histogram
+    bool can_half = false, cut_possible = false, sample_inside = false;   // sample_inside: the sample runs in the plan's first launch
+    uint32_t n_sample = 0;               // sampled pairs (two sub-pairs each)
+    int sample_W = 0, sample_L = 0;
+    uint64_t rows_cap = 0;               // rows (of 64 dwords) the row buffer holds
+    // One allocation (d_rows is its start); everything below is a part of it.  Static = written once per batch (from
+    // the lengths); the rest is rewritten by every plan, on the device.
+    uint32_t *d_rows = nullptr;          // per piece, lane-interleaved rows of 64 dwords
+    uint32_t *d_pairs = nullptr;         // static: pair ids of the class
+    uint8_t *d_cls = nullptr;            // static: their retry class
+    uint32_t *d_item = nullptr, *d_sets = nullptr, *d_slot = nullptr;   // sets: two of { histogram, cursors, column sums }, used by alternate plans
+    uint32_t set_words = 0, plan_parity = 0;
+    uint32_t *d_lay_off = nullptr, *d_lay_info = nullptr;   // the pieces in the order of the tiles: first row, column blocks | mode flags (0 = no piece)
+    uint32_t *d_piece_off = nullptr;     // the same in the order of the launch's workgroups: first row of each piece
+    uint32_t *d_piece_info = nullptr;    // column blocks of each piece | mode flags; 0 = no piece
     uint32_t *d_piece_join = nullptr;    // for the pieces of a cut tile: which slot of the join buffer they meet in
+    uint32_t *d_piece_place = nullptr;   // which place of the layout a workgroup runs (for whoever wants to look at the plan)
     uint32_t *d_join_buf = nullptr;
+    uint32_t *d_stats = nullptr;         // what the last plan decided (plan_stats)
+    uint32_t *d_sample = nullptr;        // static: a_off, a_len, b_off, b_len, list of the sample's sub-pairs, a correction per sampled pair, the count
+    int32_t *d_sample_dist = nullptr;    // the sub-pairs' distances (written by every plan)
     uint32_t *d_retry_list = nullptr, *d_retry_first = nullptr, *d_retry_cap = nullptr, *d_retry_count = nullptr;
     std::vector<diag_retry> retry;
     uint32_t parity = 0;                 // which of the two sets of retry counters the last launch used
+    bool planned = false;                // a plan has been queued
 };
+
+// what a plan decided, in device memory (dwords; read back only when somebody asks: malcs_diag_stats)
+enum { PS_NPIECES, PS_NHALF, PS_NCUT, PS_HALFMODE, PS_ERROR, PS_ROWS, PS_BLOCKS, PS_BLOCKS_HALF, PS_IT_LAST, PS_LAST_HALF,
+       PS_COLS0_LO, PS_COLS0_HI, PS_COLS1_LO, PS_COLS1_HI, PS_SAMPLE_MEAN_X16, PS_SAMPLE_SD_X16, PS_WORST,
+       PS_BALANCED, PS_MINOR_A, PS_NAB, PS_FIELDS };
 
 struct malcs_batch {
     malcs_ctx *ctx = nullptr;
@@ -187,6 +208,7 @@ struct malcs_batch {
     std::vector<uint8_t> plan_cls, plan_in_window, plan_diag_cls;   // scratch of malcs_dist_plan, kept with the object (pages)
     std::vector<uint32_t> plan_diag_pairs;
     uint32_t plan_window_longest = 0;                               // longest sequence among the pairs of the window class
+    uint64_t plan_window_blocks = 0;                                // sum of their texts' 32-column blocks (sizes the row buffer)
     std::vector<dist_bucket> dist_buckets;
     std::vector<uint32_t> band_pairs;    // pairs too long for a resident pattern: sliding-window kernel
     diag_plan diag;
@@ -210,14 +232,19 @@ int malcs_pack_launch(malcs_ctx *ctx, const uint8_t *d_syms, const uint64_t *d_s
 
 // malcs_diag.hip
 // pairs[i] goes to the window class; retry_class[i] indexes `classes` (its full-matrix launch class)
-int malcs_diag_plan(malcs_batch *b, int nlw, const std::vector<uint32_t> &pairs, const std::vector<uint8_t> &retry_class,
-                    const std::vector<diag_retry> &classes);
+// setup: once per batch, from the lengths alone (allocation, tables); plan: everything that depends on what the
+// sequences hold (common ends, sort, tiles, pieces, rows), queued on the context's stream, nothing comes back
+int malcs_diag_setup(malcs_batch *b, int nlw, const std::vector<uint32_t> &pairs, const std::vector<uint8_t> &retry_class,
+                     const std::vector<diag_retry> &classes);
+int malcs_diag_plan(malcs_batch *b);
+int malcs_diag_stats(malcs_batch *b, uint32_t *stats);                 // synchronises; PS_FIELDS dwords
 int malcs_diag_launch(malcs_batch *b, bool advance, hipEvent_t start = nullptr, hipEvent_t stop = nullptr);   // events: the launch's own start and end
 void malcs_diag_release(malcs_batch *b);
 int malcs_diag_threshold(int nlw);
 
 // malcs_dist.hip
-int malcs_dist_plan(malcs_batch *b);
+int malcs_dist_plan(malcs_batch *b);          // classes from the lengths (host) + malcs_dist_replan
+int malcs_dist_replan(malcs_batch *b);        // what depends on the sequences: the window class's plan, on the device
 int malcs_dist_launch(malcs_batch *b);
 int malcs_dist_launch_resident(malcs_batch *b);
 int malcs_dist_band(malcs_batch *b, const std::vector<uint32_t> &pairs, int32_t *host_out);

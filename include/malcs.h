@@ -71,9 +71,12 @@ int malcs_batch_create(malcs_ctx *ctx, const uint8_t *syms, uint64_t n_syms,
                        uint64_t n_pairs, int n_symbols, malcs_batch **batch);
 int malcs_batch_destroy(malcs_batch *batch);
 uint64_t malcs_batch_size(const malcs_batch *batch);
-/* Runs the distance plan of a batch again, on the planes that are already resident: launch classes, and for the window
- * class the common ends, the sort into tiles and the rows of every piece (all on the device).  The results of the
- * batch do not change; bench.py times plan + launch with it, separately from the copy to the device. */
+/* Queues the part of a batch's distance plan that depends on what its sequences hold, again, on the planes that are
+ * already resident: for the window class the common ends of every pair, the sort into tiles, the mode of the class
+ * (from a sample), the pieces and their deal to the SIMDs, the rows of every piece -- all of it kernels on the
+ * context's stream, nothing is copied back and the call does not wait.  (What follows from the LENGTHS alone -- which
+ * pair runs in which class -- is worked out once, on the host, by malcs_batch_create.)  The results of the batch do not
+ * change; bench.py times plan + launch with it: what a caller pays who computes a batch's distances once. */
 int malcs_batch_replan(malcs_batch *batch);
 
 /* ---- kernel family 1: batched distances ---------------------------------------------------
@@ -93,13 +96,20 @@ int malcs_edit_distance_launch(malcs_batch *batch);
 int malcs_edit_distance_fetch(malcs_batch *batch, int32_t *dist);
 int malcs_edit_distance_time(malcs_batch *batch, int iters, float *ms_total);
 
-/* What the planner decided for this batch (for reports; bench.py prices its roofline with it):
+/* What the planner decided for this batch (for reports; bench.py prices its roofline with it).  The plan of the window
+ * class lives in device memory; this call waits for the context's stream and copies its summary back.
  * info[0] pairs in the window class, [1] limbs (32 rows each) in the window, [2] its threshold T
- * (results <= T are final, others are redone over the full matrix; 48 when every tile runs in two-limb mode), [3] cells the window class computes
- * = sum 32 * limbs * max(m, n), [4] full-matrix cells of the whole batch = sum m * n,
+ * (results <= T are final, others are redone over the full matrix; 48 when every tile runs in two-limb mode), [3] cells
+ * the window class computes, as laid out: rows of the tile's mode x the text of the tile's longest pair, grown to whole
+ * blocks of 32 columns, [4] full-matrix cells of the whole batch = sum m * n,
  * [5] number of full-matrix launch classes, [6] tiles (64 pairs) of the window class, [7] of those, tiles in two-limb
- * mode (64 rows, threshold 48: chosen when a sample of the batch's distances stays well below it). */
-int malcs_batch_plan_info(const malcs_batch *batch, uint64_t *info8);
+ * mode (64 rows, threshold 48: chosen when a sample of the batch makes a pair beyond it improbable),
+ * [8] pieces (workgroups that have work), [9] tiles that run as two pieces, [10] workgroups of a launch (an upper bound of
+ * [8], known without asking the device), [11] the cells between the common ends of every pair as they are (rows of the
+ * mode x text columns: no growth to blocks or to the tile's longest), [12], [13] mean and standard deviation of the sample's
+ * distance estimates x 16, [14] what the fullest SIMD of a launch holds (quarters of a three-limb block), [15] whether
+ * the cuts were balanced between the SIMDs that hold one piece more and the others. */
+int malcs_batch_plan_info(malcs_batch *batch, uint64_t *info16);
 /* As _time, but only the batch's dominant kernel (the window kernel when the batch has a window class,
  * else the full-matrix launches), so that its duration can be set against rocprofv3's. */
 int malcs_edit_distance_time_kernel(malcs_batch *batch, int iters, float *ms_total);
