@@ -51,6 +51,7 @@ def _load():
         "malcs_edit_distance_time_kernel": (c.c_int, [vp, c.c_int, P(c.c_float)]),
         "malcs_edit_distance_kernel_durations": (c.c_int, [vp, c.c_int, vp]),
         "malcs_batch_plan_info": (c.c_int, [vp, P(c.c_uint64)]),
+        "malcs_batch_plan_dump": (c.c_int, [vp, c.c_int, vp, c.c_uint64, P(c.c_uint64)]),
         "malcs_edit_distance_batch": (c.c_int, [vp, vp, u64, vp, vp, vp, vp, u64, c.c_int, vp]),
         "malcs_edit_distance_noalloc": (c.c_int, [vp, vp, vp, u64, vp, vp, vp, vp, u64, c.c_int, vp]),
         "malcs_lcs_graph_batch": (c.c_int, [vp, vp, vp, P(vp)]),
@@ -68,6 +69,7 @@ def _load():
         "malcs_graphs_canonical": (c.c_int, [vp, u64, vp]),
         "malcs_graphs_timing": (c.c_int, [vp, vp]),
         "malcs_graphs_device_built": (c.c_int, [vp, P(u64), P(c.c_float)]),
+        "malcs_graphs_tie_bytes": (c.c_int, [vp, P(u64), P(u64)]),
         "malcs_relmatrix_create": (c.c_int, [vp, u64, vp, vp, vp, vp, u32, u32, u32, P(vp)]),
         "malcs_relmatrix_destroy": (c.c_int, [vp]),
         "malcs_relmatrix_pending_count": (c.c_int, [vp, P(u64)]),
@@ -268,6 +270,15 @@ class Batch:
                 "sample_mean_x16", "sample_sd_x16", "worst_simd", "balanced_cuts")
         return dict(zip(keys, (int(x) for x in info)))
 
+    def plan_dump(self, what):
+        """One of the arrays of the window class's plan (malcs_batch_plan_dump), as uint32."""
+        n = ctypes.c_uint64()
+        check(lib.malcs_batch_plan_dump(self.handle, int(what), None, 0, ctypes.byref(n)))
+        out = np.zeros(n.value, dtype=np.uint32)
+        if n.value:
+            check(lib.malcs_batch_plan_dump(self.handle, int(what), ptr(out), n.value, ctypes.byref(n)))
+        return out
+
     def lcs_nodes(self, shift=None, max_distance=None):
         """_lcs_nodes(reference_i, observed_i, shift_i, max_distance_i) for every pair: the reference's
         complete level lists (Graphs handle with runs only)."""
@@ -308,6 +319,9 @@ class Graphs:
             built, ms = ctypes.c_uint64(), ctypes.c_float()
             check(lib.malcs_graphs_device_built(handle, ctypes.byref(built), ctypes.byref(ms)))
             self.device_built, self.device_build_ms = built.value, ms.value
+            tb, tp = ctypes.c_uint64(), ctypes.c_uint64()
+            check(lib.malcs_graphs_tie_bytes(handle, ctypes.byref(tb), ctypes.byref(tp)))
+            self.tie_bytes, self.tie_pairs = tb.value, tp.value
         except Exception:
             self.close()
             raise

@@ -710,6 +710,13 @@ int malcs_batch_plan_info(malcs_batch *b, uint64_t *info)
     return MALCS_OK;
 }
 
+int malcs_batch_plan_dump(malcs_batch *b, int what, uint32_t *out, uint64_t cap, uint64_t *n_out)
+{
+    if (!b || !n_out) { malcs_set_error("NULL argument"); return MALCS_ERR_ARG; }
+    MALCS_HIP(hipSetDevice(b->ctx->device));
+    return malcs_diag_dump(b, what, out, cap, n_out);
+}
+
 int malcs_edit_distance_batch(malcs_ctx *ctx, const uint8_t *syms, uint64_t n_syms,
                               const uint64_t *a_off, const uint32_t *a_len, const uint64_t *b_off, const uint32_t *b_len,
                               uint64_t n_pairs, int n_symbols, int32_t *dist)

@@ -504,6 +504,7 @@ struct malcs_graphs {
     std::deque<pinned_vec<int32_t>> dev_words;    // graphs the device built, one buffer per chunk of pairs
     float timing[4] = {0, 0, 0, 0};               // [3]: device graph construction (malcs_gbuild.hip)
     uint64_t n_dev_built = 0;
+    uint64_t tie_bytes = 0, tie_pairs = 0;        // bit-vector path: bytes of tie-bit rows its forward pass wrote (and its backward pass read), pairs
 };
 
 // the int64 arrays of a graph the device built (rows, columns and variant positions get their shift here)
@@ -833,6 +834,7 @@ static int graph_batch(malcs_batch *b, const int64_t *shift, const int64_t *max_
                 llcs.push_back((int32_t)((m + n - D) / 2));
             }
             const uint32_t cnt = (uint32_t)work.size();
+            out->tie_bytes += used * 4ull; out->tie_pairs += cnt;
             if (d_work.alloc(cnt) || d_scoff.alloc(cnt) || d_scratch.alloc(used) || d_skip.alloc(cnt) ||
                 d_evcap.alloc(cnt) || d_evcnt.alloc(cnt) || d_evoff.alloc(cnt) || d_outoff.alloc(cnt) ||
                 d_kmin.alloc(cnt) || d_kmax.alloc(cnt) || d_rw.alloc(cnt) || d_llcs.alloc(cnt) || d_fdist.alloc(cnt)) {
@@ -1302,6 +1304,14 @@ int malcs_graphs_device_built(const malcs_graphs *g, uint64_t *count, float *ms)
     if (!g) { malcs_set_error("NULL argument"); return MALCS_ERR_ARG; }
     if (count) *count = g->n_dev_built;
     if (ms) *ms = g->timing[3];
+    return MALCS_OK;
+}
+
+int malcs_graphs_tie_bytes(const malcs_graphs *g, uint64_t *bytes, uint64_t *pairs)
+{
+    if (!g) { malcs_set_error("NULL argument"); return MALCS_ERR_ARG; }
+    if (bytes) *bytes = g->tie_bytes;
+    if (pairs) *pairs = g->tie_pairs;
     return MALCS_OK;
 }
 

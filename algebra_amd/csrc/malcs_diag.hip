@@ -843,7 +843,7 @@ int malcs_diag_setup(malcs_batch *b, int nlw, const std::vector<uint32_t> &pairs
     const size_t at_rows = carve(keep, (size_t)rows_cap * 64u);            // (includes one block of padding: the kernel prefetches unconditionally)
     const size_t at_pairs = carve(keep, count), at_cls = carve(keep, (count + 3) / 4), at_item = carve(keep, (size_t)ITEM_STRIDE * count);
     const size_t at_sets = carve(keep, 2 * (size_t)set_words);
-    const size_t at_slot = carve(keep, (size_t)n_tiles * 64);
+    const size_t at_sitem = carve(keep, (size_t)ITEM_STRIDE * n_tiles * 64), at_pub = carve(keep, PUB_HDR_WORDS + 4 * (size_t)HB);
     const size_t at_tab = carve(keep, (size_t)6 * n_launch + 4);
     const size_t at_list = carve(keep, std::max<uint32_t>(acc, 1)), at_first = carve(keep, ncls), at_cap = carve(keep, ncls);
     const size_t at_count = carve(keep, 2 * ncls);                         // two sets, used by alternate launches
@@ -854,7 +854,7 @@ int malcs_diag_setup(malcs_batch *b, int nlw, const std::vector<uint32_t> &pairs
     (void)at_rows;                                                         // the rows come first: d_rows is the allocation
     uint32_t *const base = d.d_rows;
     d.d_pairs = base + at_pairs; d.d_cls = reinterpret_cast<uint8_t *>(base + at_cls); d.d_item = base + at_item;
-    d.d_sets = base + at_sets; d.set_words = set_words; d.d_slot = base + at_slot;
+    d.d_sets = base + at_sets; d.set_words = set_words; d.d_sitem = base + at_sitem; d.d_pub = base + at_pub;
     d.d_piece_off = base + at_tab; d.d_piece_info = d.d_piece_off + n_launch + 1; d.d_piece_join = d.d_piece_info + n_launch;
     d.d_piece_place = d.d_piece_join + n_launch; d.d_lay_off = d.d_piece_place + n_launch; d.d_lay_info = d.d_lay_off + n_launch;
     d.d_join_buf = base + at_jbuf; d.d_stats = base + at_stats;
@@ -895,7 +895,7 @@ int malcs_diag_plan(malcs_batch *b)
     A.pairs = d.d_pairs; A.cls = d.d_cls; A.item = d.d_item; A.sets = d.d_sets; A.set_words = d.set_words;
     d.plan_parity ^= 1u;
     A.parity = d.plan_parity;
-    A.slot = d.d_slot; A.lay_off = d.d_lay_off; A.lay_info = d.d_lay_info; A.piece_off = d.d_piece_off; A.piece_info = d.d_piece_info;
+    A.sitem = d.d_sitem; A.pub = d.d_pub; A.lay_off = d.d_lay_off; A.lay_info = d.d_lay_info; A.piece_off = d.d_piece_off; A.piece_info = d.d_piece_info;
     A.piece_join = d.d_piece_join; A.piece_place = d.d_piece_place; A.retry_count = d.d_retry_count; A.stats = d.d_stats; A.rows = d.d_rows;
     A.sample = d.d_sample; A.sample_dist = d.d_sample_dist;
     A.HB = HB; A.count = count; A.n_tiles = d.n_tiles; A.n_launch = d.n_launch; A.S = (uint32_t)std::max(1, ctx->prop.multiProcessorCount) * 4u;
@@ -938,17 +938,50 @@ int malcs_diag_plan(malcs_batch *b)
     MALCS_HIP(hipGetLastError());
     hipLaunchKernelGGL(k_plan_scatter, dim3((count + 1023u) / 1024u), dim3(1024), 3 * hist_lds, st, A);
     MALCS_HIP(hipGetLastError());
-    // the first workgroup deals the pieces to the SIMDs, the others write the rows of four places each
-    const dim3 g_layout(1u + (d.n_launch + 3u) / 4u);
+    // the first workgroup deals the pieces to the SIMDs, the others write the rows of a few places each
+    int wpp = 4;
+    if (const char *env = getenv("MALCS_LAYOUT_WPP")) wpp = atoi(env);     // dev: waves per place
+    const uint32_t places = 16u / (uint32_t)wpp;
+    const dim3 g_layout(1u + (d.n_launch + places - 1u) / places);
     const size_t layout_lds = ((size_t)std::max(2u * H2, RANK_BINS) + DEAL_MAX) * sizeof(uint32_t);
+#define LAYOUT(NPV, WPPV) hipLaunchKernelGGL((k_diag_layout<NPV, WPPV>), g_layout, dim3(1024), layout_lds, st, A)
     switch (NP) {
-    case 2: hipLaunchKernelGGL(k_diag_layout<2>, g_layout, dim3(1024), layout_lds, st, A); break;
-    case 3: hipLaunchKernelGGL(k_diag_layout<3>, g_layout, dim3(1024), layout_lds, st, A); break;
-    case 4: hipLaunchKernelGGL(k_diag_layout<4>, g_layout, dim3(1024), layout_lds, st, A); break;
+    case 2: if (wpp == 1) LAYOUT(2, 1); else if (wpp == 2) LAYOUT(2, 2); else LAYOUT(2, 4); break;
+    case 3: LAYOUT(3, 4); break;
+    case 4: LAYOUT(4, 4); break;
     }
+#undef LAYOUT
     MALCS_HIP(hipGetLastError());
     d.parity = 0;                                                          // the deal has zeroed both sets of retry counters
     d.planned = true;
+    return MALCS_OK;
+}
+
+// Copies one of the plan's device arrays to the host (tests and dev tools look at the plan with it).  `what`: 0 item records
+// in pair order, 1 item records in slot order, 2 lay_off, 3 lay_info, 4 piece_off, 5 piece_info, 6 piece_join,
+// 7 piece_place, 8 the published plan.  Returns the number of dwords the array has; copies min(that, cap).
+int malcs_diag_dump(malcs_batch *b, int what, uint32_t *out, uint64_t cap, uint64_t *n_out)
+{
+    diag_plan &d = b->diag;
+    *n_out = 0;
+    if (!d.nlw || !d.planned) return MALCS_OK;
+    const uint32_t *src = nullptr;
+    uint64_t n = 0;
+    switch (what) {
+    case 0: src = d.d_item; n = (uint64_t)ITEM_STRIDE * d.n_pairs; break;
+    case 1: src = d.d_sitem; n = (uint64_t)ITEM_STRIDE * d.n_tiles * 64u; break;
+    case 2: src = d.d_lay_off; n = d.n_launch; break;
+    case 3: src = d.d_lay_info; n = d.n_launch; break;
+    case 4: src = d.d_piece_off; n = d.n_launch; break;
+    case 5: src = d.d_piece_info; n = d.n_launch; break;
+    case 6: src = d.d_piece_join; n = d.n_launch; break;
+    case 7: src = d.d_piece_place; n = d.n_launch; break;
+    case 8: src = d.d_pub; n = PUB_HDR_WORDS + 4ull * d.HB; break;
+    default: malcs_set_error("no such plan array"); return MALCS_ERR_ARG;
+    }
+    *n_out = n;
+    MALCS_HIP(hipStreamSynchronize(b->ctx->stream));
+    if (out && cap) MALCS_HIP(hipMemcpy(out, src, std::min(n, cap) * sizeof(uint32_t), hipMemcpyDeviceToHost));
     return MALCS_OK;
 }
 

@@ -171,7 +171,7 @@ struct diag_plan {
     uint32_t *d_rows = nullptr;          // per piece, lane-interleaved rows of 64 dwords
     uint32_t *d_pairs = nullptr;         // static: pair ids of the class
     uint8_t *d_cls = nullptr;            // static: their retry class
-    uint32_t *d_item = nullptr, *d_sets = nullptr, *d_slot = nullptr;   // sets: two of { histogram, cursors, column sums }, used by alternate plans
+    uint32_t *d_item = nullptr, *d_sitem = nullptr, *d_pub = nullptr, *d_sets = nullptr;   // item records by pair / by slot; the published plan;   // sets: two of { histogram, cursors, column sums }, used by alternate plans
     uint32_t set_words = 0, plan_parity = 0;
     uint32_t *d_lay_off = nullptr, *d_lay_info = nullptr;   // the pieces in the order of the tiles: first row, column blocks | mode flags (0 = no piece)
     uint32_t *d_piece_off = nullptr;     // the same in the order of the launch's workgroups: first row of each piece
@@ -237,7 +237,8 @@ int malcs_pack_launch(malcs_ctx *ctx, const uint8_t *d_syms, const uint64_t *d_s
 int malcs_diag_setup(malcs_batch *b, int nlw, const std::vector<uint32_t> &pairs, const std::vector<uint8_t> &retry_class,
                      const std::vector<diag_retry> &classes);
 int malcs_diag_plan(malcs_batch *b);
-int malcs_diag_stats(malcs_batch *b, uint32_t *stats);                 // synchronises; PS_FIELDS dwords
+int malcs_diag_stats(malcs_batch *b, uint32_t *stats);
+int malcs_diag_dump(malcs_batch *b, int what, uint32_t *out, uint64_t cap, uint64_t *n_out);                 // synchronises; PS_FIELDS dwords
 int malcs_diag_launch(malcs_batch *b, bool advance, hipEvent_t start = nullptr, hipEvent_t stop = nullptr);   // events: the launch's own start and end
 void malcs_diag_release(malcs_batch *b);
 int malcs_diag_threshold(int nlw);

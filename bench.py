@@ -3,8 +3,11 @@
 
     python bench.py [--gpus N] [--steps K] [--warmup W] [--pairs P]
 
-One "step" is one pass of kernel family 1 over a batch of P = 100 000 pairs of ~1 kb windows with
-~2 % indels, the packed bit-plane arena already resident in HBM.  With N > 1 there is
+One "step" is what a caller pays who computes the distances of a batch ONCE: the whole plan of the batch (on the device:
+common ends of every pair, sort into tiles, mode of the class from a sample, pieces and their deal to the SIMDs, rows of
+every piece) + one pass of kernel family 1, over a batch of P = 100 000 pairs of ~1 kb windows with ~2 % indels (SURVEY
+8(d) C2).  Resident in HBM when the timed region starts: the packed bit-plane arena (2 bit per base) and the per-pair
+offset / length tables -- the inputs, nothing derived from what the sequences hold.  With N > 1 there is
 one rank per GPU: started by a launcher (torch.distributed.run sets RANK / WORLD_SIZE / MASTER_*) or, when there is
 none, by this script itself (N child processes, started before anything touches the GPU); every rank owns its own batch of P pairs
 (independent pairs, no data-path collective => weak scaling) and the job rate is all pairs of
@@ -155,6 +158,71 @@ def extra_configs(ctx, _native, gen):
     return out
 
 
+def long_window_configs(ctx, _native, gen):
+    """BASELINE configs 3 and 5: LCS graphs of long windows.  Two device paths build them (identical
+    graphs): the output-sensitive sweeps (default for similar windows: no predecessor masks at all, a table of furthest
+    points of (D + 1)(D + 2) / 2 words per pair written by the backward sweep and read by the forward one) and the
+    bit-vector kernels (2 bits of tie masks per band cell, written by the forward pass, read by the backward pass)."""
+    from algebra_amd.lcs.encoding import encode_pairs
+    out = {}
+
+    def run(pairs, reps, bitvector):
+        if bitvector:
+            os.environ["MALCS_SWEEP_DMAX"] = "-1"
+        try:
+            syms, ao, al, bo, bl, ns = encode_pairs(pairs)
+            cells = float((al.astype(np.float64) * bl).sum())
+            bt = _native.Batch(ctx, syms, ao, al, bo, bl, ns)
+            bt.graphs().close()                                    # warm-up
+            walls = []
+            for _ in range(reps):
+                t0 = time.perf_counter()
+                g = bt.graphs()
+                walls.append(time.perf_counter() - t0)
+                if len(walls) < reps:
+                    g.close()
+            wall = sorted(walls)[len(walls) // 2]
+            dist = g.distance.astype(np.float64)
+            rec = {"pairs": len(pairs), "cells_full_matrix": cells, "cells_per_s": round(cells / wall, 1), "wall_ms": round(wall * 1e3, 2),
+                   "distance": [int(x) for x in g.distance[:4]], "nodes": [int(x) for x in g.counts[:4, 2]], "edges": [int(x) for x in g.counts[:4, 3]],
+                   "pass1_ms": round(float(g.timing[0]), 3), "pass2_ms": round(float(g.timing[1]), 3),
+                   "build_device_ms": round(float(g.device_build_ms), 3), "graphs_built_on_device": int(g.device_built),
+                   "build_host_ms": round(float(g.timing[2]), 2)}
+            rec["other_ms"] = round(rec["wall_ms"] - rec["pass1_ms"] - rec["pass2_ms"] - rec["build_host_ms"], 2)   # copies, allocation, read-out
+            if bitvector:
+                rec["device_path"] = "bit-vector kernels k_lcs_forward / k_lcs_reach (band from the exact distance)"
+                rec["tie_mask_bytes_written"] = int(g.tie_bytes)
+                rec["tie_mask_bytes_read"] = int(g.tie_bytes)
+                rec["band_bytes_algorithmic"] = "0.25 B per band cell: the rows are the band"
+                for stage, key in (("forward_write", "pass1_ms"), ("reach_read", "pass2_ms")):
+                    if rec[key] > 0:
+                        gbs = g.tie_bytes / (rec[key] * 1e-3) / 1e9
+                        rec["roofline_" + stage] = {"bound": "hbm", "achieved": round(gbs, 1), "peak": 8000.0, "unit": "GB/s", "frac": round(gbs / 8000.0, 4)}
+            else:
+                table = float(((dist + 1) * (dist + 2) / 2 * 4).sum())
+                rec["device_path"] = "furthest-reaching sweeps k_sweep_reach (backwards, keeps the table) / k_sweep_runs (forwards); no predecessor masks"
+                rec["tie_mask_bytes_written"] = 0
+                rec["reach_table_bytes"] = int(table)
+                rec["bound"] = "latency of one workgroup per pair (D + 1 dependent budgets); not a bandwidth kernel"
+            g.close()
+            bt.close()
+            return rec
+        finally:
+            os.environ.pop("MALCS_SWEEP_DMAX", None)
+
+    c3 = [gen.tandem_pair(np.random.RandomState(300 + s), 10000, 20) for s in range(16)]
+    out["c3"] = {"workload": "16 pairs, 10 kb reference with 20 tandem-repeat tracts, copy numbers changed + 0.5 % indels (tests/gen.py tandem_pair, seeds 300-315)",
+                 "sweeps": run(c3, 5, False), "bit_vector": run(c3, 3, True)}
+    sparse = [gen.large_pair({"kind": "few", "seed": 50 + i, "length": 1000000, "events": 20}) for i in range(4)]
+    rs = np.random.RandomState(5)
+    a = gen.random_seq(rs, 1000000)
+    dense = [(a, gen.mutate(rs, a, 0.01, 0.01))]
+    out["c5"] = {"workload": "1 Mb pairs: (i) 4 pairs with 20 small indels, (ii) 1 pair at 2 % indels",
+                 "i_sweeps": run(sparse, 3, False), "i_bit_vector": run(sparse, 2, True),
+                 "ii_sweeps": run(dense, 2, False), "ii_bit_vector": run(dense, 1, True)}
+    return out
+
+
 def relation_matrix(ctx, gen, rank, world, comm, gather, fence, all_max):
     """BASELINE config 4, the other half of the metric: the 5 000 x 5 000 `graph_based.compare` matrix over clustered
     variants in a 100 kb locus.  Upper-triangular 256 x 256 tiles are dealt round-robin to the ranks; the one
@@ -189,6 +257,8 @@ def relation_matrix(ctx, gen, rank, world, comm, gather, fence, all_max):
     fence()
     pairs = len(graphs) * (len(graphs) - 1) // 2
     return {"variants": len(graphs), "pairs": pairs, "n_gpus": world, "relations_per_s": round(pairs / seconds, 1),
+            "relations_per_s_end_to_end": round(pairs / (seconds + t_graphs + t_columns), 1),
+            "end_to_end_covers": "supremal graphs of the variants (from_variant_batch) + their per-variant columns + one matrix",
             "pairs_reaching_dp_on_rank0": stats["dp_pairs"] // reps, "supremal_graphs_s": round(t_graphs, 3),
             "per_variant_columns_s": round(t_columns, 4),
             "matrix_s_covers": "tiles + pre-filters, undecided pairs decided on the device, all-gather, assembly, the full matrix in (pinned) host memory; graphs and their per-variant columns are made before it",
@@ -281,17 +351,21 @@ def main():
     # The card idles at low clocks and takes tens of milliseconds of work to leave them (a launch measured over 50 cold
     # repetitions is 12 % slower than over 1 000): `--preheat-ms` of untimed steps come before the W warm-up steps, so
     # that a short run (--steps 20) measures the same machine state as a long one.
+    def step():
+        batch.replan()                             # everything that depends on the sequences, queued on the device
+        batch.launch_distances()
+
     t_heat = time.perf_counter()
     while (time.perf_counter() - t_heat) * 1e3 < args.preheat_ms:
-        for _ in range(50):
-            batch.launch_distances()
+        for _ in range(20):
+            step()
         ctx.sync()
     for _ in range(args.warmup):
-        batch.launch_distances()
+        step()
     fence()
     t0 = time.perf_counter()
     for _ in range(args.steps):
-        batch.launch_distances()
+        step()
     torch.cuda.synchronize()                       # this rank's K steps are done ...
     elapsed = time.perf_counter() - t0
     fence()                                        # ... and the job is done when the slowest rank is: MAX below
@@ -314,7 +388,7 @@ def main():
     plan = batch.plan_info()
     # (at least 500 launches each, whatever K is: 20 launches of 20 us are too few for an average)
     launches = max(args.steps, 500)
-    step_ms = batch.time_distances(launches) / launches
+    step_ms = batch.time_distances(launches) / launches           # the launch alone, replayed over the rows of the last plan
     batch.time_dominant_kernel(100)
     back_to_back_ms = batch.time_dominant_kernel(launches) / launches     # one event pair around all launches: + the gap between two kernels
     kernel_timing = {"back_to_back_ms": round(back_to_back_ms, 4)}
@@ -330,13 +404,18 @@ def main():
     else:
         kernel_ms = back_to_back_ms
         kernel_timing["how"] = "one HIP event pair around all launches / their number"
+    padded_cells = None
     if plan["window_pairs"]:
-        kernel_cells = float(plan["window_cells"])
+        # priced on the cells between the common ends of every pair AS THEY ARE; what the kernel really runs (texts grown
+        # to whole blocks of 32 columns and to the longest of their tile) is reported beside it
+        kernel_cells = float(plan["window_cells_unpadded"])
+        padded_cells = float(plan["window_cells"])
         kernel_name = f"k_llcs_diag<{plan['window_limbs']},2,true>"
         rows = (f"64 rows (two-limb mode, {plan['two_limb_tiles']} of {plan['window_tiles']} tiles; the others "
                 f"{32 * plan['window_limbs']})" if plan["two_limb_tiles"] else f"{32 * plan['window_limbs']} rows")
         algorithmic = (f"{OPS_PER_CELL} lane-op/cell x {kernel_cells:.4g} window cells/launch "
-                       f"({rows} x text length without the pair's common ends, {plan['window_pairs']} pairs; "
+                       f"({rows} x text columns between the pair's common ends, unpadded, {plan['window_pairs']} pairs; "
+                       f"as laid out, grown to whole blocks and to the tile's longest: {padded_cells:.4g}; "
                        f"{cells:.4g} full-matrix-equivalent cells)")
     else:
         kernel_cells = cells
@@ -344,20 +423,13 @@ def main():
         algorithmic = f"{OPS_PER_CELL} lane-op/cell x {cells:.4g} cells/launch"
     achieved = kernel_cells * OPS_PER_CELL / (kernel_ms * 1e-3) / 1e12
 
-    # What a caller pays who computes a batch's distances once (rank 0's figures; every rank does the same work):
-    #   plan_inclusive  planes already resident in HBM: the whole plan (classes on the host; common ends, sort into tiles,
-    #                   rows of every piece on the device) + launch, per batch;
+    # Beside the headline (rank 0's figures; every rank does the same work):
+    #   resident_replay the launch alone over the rows of a plan that is already there (the figure of the earlier rounds'
+    #                   headline: what a caller gets who computes the SAME batch again and again);
     #   end_to_end      from the caller's host buffers (one byte per symbol, pageable numpy arrays) to distances in host
-    #                   memory: malcs_batch_create (planes packed on the host's cores, copied packed, plan) + launch +
-    #                   fetch + destroy.  PCIe-inclusive: never `value`.
+    #                   memory: malcs_batch_create (planes packed on the host's cores, copied packed, classes from the
+    #                   lengths, plan) + launch + fetch + destroy.  PCIe-inclusive: never `value`.
     reps = 20
-    batch.replan(); batch.launch_distances(); ctx.sync()
-    t0 = time.perf_counter()
-    for _ in range(reps):
-        batch.replan()
-        batch.launch_distances()
-    ctx.sync()
-    plan_s = (time.perf_counter() - t0) / reps
     assert np.array_equal(batch.fetch_distances(), d)
     for _ in range(2):
         _native.Batch(ctx, syms, a_off, a_len, b_off, b_len, 4).close()
@@ -420,7 +492,7 @@ def main():
         # HBM bytes per launch of that kernel: NOT measured in this run (counters need rocprofv3 passes of their own);
         # read from the committed PMC summary of the same command and tagged with its source
         traffic, traffic_source = None, None
-        for tag in ("r02", "r01"):
+        for tag in ("r03", "r02", "r01"):
             pmc = os.path.join(ROOT, "profiles", f"{tag}_pmc.json")
             if os.path.exists(pmc) and args.pairs == 100000:
                 with open(pmc) as f:
@@ -428,6 +500,7 @@ def main():
                 if traffic is not None:
                     traffic_source = f"profiles/{tag}_pmc.json"
                     break
+        replay_s = step_ms * 1e-3
         out = {
             "metric": "GCUPS (batched LCS edit distance, 1 kb windows)",
             "value": round(total_cells * args.steps / elapsed / 1e9, 1),
@@ -437,19 +510,27 @@ def main():
             "ms_per_step": round(elapsed / args.steps * 1e3, 4),
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "u32", "data": "synthetic",
-            "config": {"workload": f"C2: {args.pairs} pairs/GPU, 1 kb reference windows, ~2% indels (seed 2+rank), "
-                                   "packed bit planes resident in HBM", "pairs_per_gpu": args.pairs,
+            "config": {"workload": f"C2: {args.pairs} pairs/GPU, 1 kb reference windows, ~2% indels (seed 2+rank); resident in HBM "
+                                   "when a step starts: the packed bit planes (2 bit/base) and the per-pair offset / length "
+                                   "tables, nothing derived from the sequences; a step = the batch's plan on the device "
+                                   "(common ends, sort into tiles, sample, pieces, rows) + the distance kernels",
+                       "pairs_per_gpu": args.pairs,
                        "parallelism": f"independent pairs x {world} rank(s)", "device": name},
             "mean_distance": round(mean_distance, 3),
             "roofline": {"bound": "valu", "achieved": round(achieved, 2), "peak": round(PEAK_LANE_OPS / 1e12, 1),
                          "unit": "T int32 lane-op/s", "frac": round(achieved * 1e12 / PEAK_LANE_OPS, 4),
                          "traffic": traffic, "traffic_source": traffic_source, "kernel": kernel_name, "kernel_ms": round(kernel_ms, 4),
                          "kernel_timing": kernel_timing, "frac_back_to_back": round(kernel_cells * OPS_PER_CELL / (back_to_back_ms * 1e-3) / PEAK_LANE_OPS, 4),
-                         "step_ms_hip_events": round(step_ms, 4), "launches_timed": launches, "algorithmic": algorithmic},
+                         "launches_timed": launches, "algorithmic": algorithmic,
+                         "cells_as_laid_out": padded_cells,
+                         "frac_on_cells_as_laid_out": None if padded_cells is None else round(padded_cells * OPS_PER_CELL / (kernel_ms * 1e-3) / PEAK_LANE_OPS, 4)},
             "plan": plan,
-            "plan_inclusive": {"pairs_per_s": round(args.pairs / plan_s, 1), "ms": round(plan_s * 1e3, 3),
-                               "what": "per batch, planes resident in HBM: distance plan (host classes; device: common ends, "
-                                       "sort into tiles, rows of every piece) + launch"},
+            "plan_inclusive": {"pairs_per_s": round(args.pairs * world * args.steps / elapsed, 1), "ms": round(elapsed / args.steps * 1e3, 4),
+                               "what": "= the headline: per batch, plan on the device + launch, nothing copied back"},
+            "resident_replay": {"pairs_per_s": round(args.pairs / replay_s, 1), "ms": round(step_ms, 4),
+                                "GCUPS": round(cells / replay_s / 1e9, 1),
+                                "what": "the distance kernels alone, replayed over the rows of a plan that is already there (HIP events, "
+                                        f"{launches} launches): the earlier rounds' headline, not what a caller of one batch gets"},
             "end_to_end": {"pairs_per_s": round(args.pairs / e2e_s, 1), "ms": round(e2e_s * 1e3, 3),
                            "what": f"per batch, from {syms.nbytes / 1e6:.0f} MB of host bytes (pageable) to distances in host memory: "
                                    "create (pack on host cores, copy packed, plan) + launch + fetch + destroy"},
@@ -461,14 +542,26 @@ def main():
             out["extra"] = {"c4_relation_matrix": {"error": matrix_error}}
         if world == 1 and not args.no_extra and matrix is not None:
             out["extra"].update(extra_configs(ctx, _native, gen))
+            try:
+                out["extra"].update(long_window_configs(ctx, _native, gen))
+            except Exception as e:                                  # noqa: BLE001 -- reported beside the headline, not instead of it
+                out["extra"]["c3_c5_error"] = f"{type(e).__name__}: {e}"
         if world == 1 and not args.no_cpu_baseline:                # rank 0 at N = 1 only
             out["cpu_baseline"] = cpu_baseline(data, cells / args.pairs)
             out["end_to_end"]["vs_cpu_port"] = round(out["end_to_end"]["pairs_per_s"] / out["cpu_baseline"]["pairs_per_s"], 2)
         print(json.dumps(out), flush=True)
 
     if hung or (world > 1 and matrix_error is not None):
+        # the headline is printed; the job FAILED all the same (3: the relation matrix raised, 4: it did not come back) --
+        # no clean shutdown: a communicator that hangs may never return
         sys.stdout.flush()
-        os._exit(0)                                   # the headline stands; do not wait on a communicator that may never return
+        sys.stderr.write(f"bench.py: relation matrix failed on rank {rank}: {matrix_error}\n")
+        sys.stderr.flush()
+        os._exit(4 if hung else 3)
+    if matrix_error is not None:
+        sys.stderr.write(f"bench.py: relation matrix failed: {matrix_error}\n")
+        batch.close(); ctx.close()
+        sys.exit(3)
     batch.close()
     ctx.close()
     if dist is not None:

@@ -110,6 +110,12 @@ int malcs_edit_distance_time(malcs_batch *batch, int iters, float *ms_total);
  * distance estimates x 16, [14] what the fullest SIMD of a launch holds (quarters of a three-limb block), [15] whether
  * the cuts were balanced between the SIMDs that hold one piece more and the others. */
 int malcs_batch_plan_info(malcs_batch *batch, uint64_t *info16);
+/* For tests and reports: copies one of the arrays of the window class's plan from device memory (waits for the context's
+ * stream).  what: 0 per-pair records in pair order (16 dwords each: pattern / text offset, rows, columns, ... blocks), 1 the
+ * same in slot order (tile = 64 consecutive slots), 2 / 3 first row and blocks | flags of every place of the layout,
+ * 4 - 7 first row, blocks | flags, join slot and place of the piece every workgroup of a launch runs, 8 the plan's header
+ * and histogram scans.  *n_dwords = size of the array; at most `cap` dwords are copied.  No counterpart in the reference. */
+int malcs_batch_plan_dump(malcs_batch *batch, int what, uint32_t *out, uint64_t cap, uint64_t *n_dwords);
 /* As _time, but only the batch's dominant kernel (the window kernel when the batch has a window class,
  * else the full-matrix launches), so that its duration can be set against rocprofv3's. */
 int malcs_edit_distance_time_kernel(malcs_batch *batch, int iters, float *ms_total);
@@ -220,6 +226,9 @@ int malcs_graphs_timing(const malcs_graphs *graphs, float *out3);
  * the runs, dominance edges, splits, numbering -- the host only copies the arrays home), and the kernels'
  * milliseconds (HIP events); the others went through the host half.  Either pointer may be NULL. */
 int malcs_graphs_device_built(const malcs_graphs *graphs, uint64_t *count, float *ms);
+/* For reports: bytes of tie-bit rows (2 bits per stored DP cell) that the bit-vector path's forward pass wrote and its
+ * backward pass read back for this handle, and how many pairs took that path (0 / 0 when all pairs took the sweeps). */
+int malcs_graphs_tie_bytes(const malcs_graphs *graphs, uint64_t *bytes, uint64_t *pairs);
 
 /* ---- kernel family 3: tiles of the all-vs-all relation matrix -----------------------------------
  * Stands in for graph_based.compare (algebra/relations/graph_based.py:33-79) over all pairs of a list of n LCS graphs

@@ -156,3 +156,70 @@ def gloo_gather(dist):
         dist.all_gather_into_tensor(recv, send)
         return recv.numpy()
     return gather
+
+
+def check_window_plan(batch):
+    """What the plan of a batch's window class (made on the device, malcs_plan.inc) must satisfy, read back through
+    malcs_batch_plan_dump: the slots hold every pair of the class once, sorted by (group, blocks); the pieces of a tile cover
+    its blocks exactly and their rows do not overlap; every workgroup's table entry is its piece's place; the row buffer
+    holds them all.  Returns a short summary."""
+    import numpy as np
+    info = batch.plan_info()
+    if not info["window_pairs"]:
+        return {"window_pairs": 0}
+    count, n_tiles, L = info["window_pairs"], info["window_tiles"], info["workgroups"]
+    item = batch.plan_dump(0).reshape(count, 16)
+    sitem = batch.plan_dump(1).reshape(n_tiles * 64, 16)
+    lay_off, lay_info = batch.plan_dump(2), batch.plan_dump(3)
+    piece_off, piece_info, piece_join, piece_place = (batch.plan_dump(k) for k in (4, 5, 6, 7))
+    PID, ITERS, DELTA = 9, 8, 7
+    # slots: a permutation of the pairs, empty slots only at the end of the last tile
+    used = sitem[:count]
+    assert (sitem[count:, PID] == 0xffffffff).all(), "empty slots"
+    assert (used[:, PID] != 0xffffffff).all()
+    assert len(np.unique(used[:, PID])) == count, "a pair sits in two slots"
+    key_item = {tuple(r[:9]) for r in item[:0]}                      # (records are compared through sorting below)
+    a = np.sort(item[:, :9].view([("", item.dtype)] * 9), axis=0)
+    b = np.sort(np.ascontiguousarray(used[:, :9]).view([("", used.dtype)] * 9), axis=0)
+    assert (a == b).all(), "the sorted records are not the records"
+    two = L == 2 * n_tiles
+    half_mode = info["two_limb_tiles"] > 0
+    grp = (used[:, DELTA] > 48).astype(np.int64) if half_mode else np.zeros(count, np.int64)
+    order_key = grp * (1 << 20) + used[:, ITERS].astype(np.int64) if half_mode else used[:, ITERS].astype(np.int64) * 2 + (used[:, DELTA] > 48)
+    assert (np.diff(order_key) >= 0).all(), "slots are not sorted"
+    # tiles and their pieces
+    blocks_mask = (1 << 28) - 1
+    rows_fixed = 4 + (info["window_limbs"] - 1) * 2                    # (DNA: two planes; the check is used with DNA batches)
+    spans = []
+    n_pieces = 0
+    for t in range(n_tiles):
+        lo, hi = 64 * t, min(64 * t + 64, count)
+        longest = int(used[lo:hi, ITERS].max())
+        places = [2 * t, 2 * t + 1] if two else [t]
+        got = [(int(lay_info[j]) & blocks_mask, int(lay_info[j]) >> 28, int(lay_off[j])) for j in places if lay_info[j]]
+        assert got, t
+        assert sum(g[0] for g in got) == longest, ("blocks of tile", t, got, longest)
+        if len(got) == 2:
+            assert got[0][1] & 0xC == 0xC and got[1][1] & 0xE == 0xE, "flags of a cut tile"     # half | joined (| back)
+            assert min(g[0] for g in got) >= 2
+        for blocks, _, off in got:
+            spans.append((off, off + rows_fixed + blocks * 4))
+        n_pieces += len(got)
+    spans.sort()
+    for (a0, a1), (b0, b1) in zip(spans, spans[1:]):
+        assert a1 <= b0, "rows of two pieces overlap"
+    assert n_pieces == info["pieces"]
+    # the table of the launch: every piece once
+    live = piece_info != 0
+    assert int(live.sum()) == n_pieces
+    places = piece_place[live]
+    assert len(np.unique(places)) == n_pieces
+    assert (piece_info[live] == lay_info[places]).all() and (piece_off[live] == lay_off[places]).all()
+    assert (piece_join[live] == (places >> 1 if two else places)).all()
+    # loads of the SIMDs (workgroups w, w + S, ... share one)
+    S = 1024
+    cost = (piece_info & blocks_mask).astype(np.int64) * np.where(piece_info >> 31, 3, 4)
+    load = np.zeros(S, np.int64)
+    np.add.at(load, np.arange(L) % S, cost)
+    return {"pieces": n_pieces, "tiles": n_tiles, "rows": spans[-1][1], "two_limb_tiles": info["two_limb_tiles"],
+            "simd_load_max": int(load.max()), "simd_load_mean": float(load.mean()), "reported_worst": info["worst_simd"]}
