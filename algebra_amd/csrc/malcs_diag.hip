@@ -788,7 +788,13 @@ int malcs_diag_setup(malcs_batch *b, int nlw, const std::vector<uint32_t> &pairs
     // the sample: pairs at equal distances through the class, each as two sub-pairs (cut at the block nearest the
     // middle of either sequence); all sub-pairs in ONE full-matrix class, the narrowest their longest allows -- the
     // sample is a few hundred waves that run side by side, so its time is the time of one wave: columns x limbs
-    std::vector<uint32_t> sample;                            // arrays of 2 n_sample entries: a_off, a_len, b_off, b_len, list; n_sample: correction
+    // The sample: pairs at equal distances through the class, each as SAMPLE_PARTS sub-pairs (cut at block boundaries of
+    // the arena: a at the boundaries nearest the equal parts of its length, b at the boundaries nearest the same fractions
+    // of its own) in SAMPLE_SLOTS places (the places of a pair sit side by side in a wave; places beyond the parts are empty).  A cut is up
+    // to 16 symbols off the alignment's own, which the parts on either side pay for with as many insertions or deletions:
+    // known here, taken off again on the device.  All sub-pairs run in ONE full-matrix class, the narrowest their longest
+    // allows -- the sample is a few hundred waves that run side by side, so its time is the time of one wave: columns x limbs.
+    std::vector<uint32_t> sample;                            // a_off, a_len, b_off, b_len, list (SAMPLE_SLOTS n_sample each); n_sample corrections
     uint32_t n_sample = 0;
     int sW = 1, sL = 1;
     const char *env_half = getenv("MALCS_DIAG_HALF");
@@ -796,25 +802,30 @@ int malcs_diag_setup(malcs_batch *b, int nlw, const std::vector<uint32_t> &pairs
     if (can_half && !forced && count >= 4096) {
         const size_t stride = count / 1024;
         n_sample = (uint32_t)((count - stride / 2 + stride - 1) / stride);
-        sample.resize((size_t)11 * n_sample);
-        uint32_t *sa_off = sample.data(), *sa_len = sa_off + 2 * (size_t)n_sample, *sb_off = sa_len + 2 * (size_t)n_sample,
-                 *sb_len = sb_off + 2 * (size_t)n_sample, *list = sb_len + 2 * (size_t)n_sample, *corr = list + 2 * (size_t)n_sample;
+        const size_t n4 = (size_t)SAMPLE_SLOTS * n_sample;
+        sample.assign(5 * n4 + n_sample, 0u);
+        uint32_t *sa_off = sample.data(), *sa_len = sa_off + n4, *sb_off = sa_len + n4, *sb_len = sb_off + n4, *list = sb_len + n4, *corr = list + n4;
         uint32_t longest = 0, k = 0;
         for (size_t i = stride / 2; i < count && k < n_sample; i += stride, k++) {
             const uint32_t pid = pairs[i];
             const uint32_t la = b->a_len[pid], lb = b->b_len[pid];
-            // The second parts start at block boundaries of the arena: a is cut at the boundary nearest its middle, b at
-            // the boundary nearest the same fraction of its length.  That is up to 16 symbols off, which either part
-            // pays for with as many insertions or deletions: known here, taken off again by the deal kernel.
-            const uint32_t ra = 32u * ((la / 32u + 1u) / 2u);
-            const uint32_t ideal = (uint32_t)((uint64_t)ra * lb / std::max(la, 1u));
-            const uint32_t rb = std::min(32u * ((ideal + 16u) / 32u), 32u * (lb / 32u));
-            corr[k] = 2u * (rb > ideal ? rb - ideal : ideal - rb);
-            sa_off[2 * k] = b->a_off[pid]; sa_len[2 * k] = ra; sb_off[2 * k] = b->b_off[pid]; sb_len[2 * k] = rb;
-            sa_off[2 * k + 1] = b->a_off[pid] + (ra / 32u) * NP; sa_len[2 * k + 1] = la - ra;
-            sb_off[2 * k + 1] = b->b_off[pid] + (rb / 32u) * NP; sb_len[2 * k + 1] = lb - rb;
-            list[2 * k] = 2 * k; list[2 * k + 1] = 2 * k + 1;
-            longest = std::max(longest, std::max(std::min(ra, rb), std::min(la - ra, lb - rb)));
+            uint32_t ca = 0, cb = 0;                             // where the part starts
+            for (uint32_t part = 0; part < SAMPLE_PARTS; part++) {
+                uint32_t ea = la, eb = lb;                       // ... and ends
+                if (part + 1 < SAMPLE_PARTS) {
+                    ea = std::max(ca, 32u * (uint32_t)(((uint64_t)la * (part + 1) / SAMPLE_PARTS + 16u) / 32u));
+                    ea = std::min(ea, 32u * (la / 32u));
+                    const uint32_t ideal = (uint32_t)((uint64_t)ea * lb / std::max(la, 1u));
+                    eb = std::min(std::max(cb, 32u * ((ideal + 16u) / 32u)), 32u * (lb / 32u));
+                    corr[k] += 2u * (eb > ideal ? eb - ideal : ideal - eb);
+                }
+                const size_t at = (size_t)SAMPLE_SLOTS * k + part;
+                sa_off[at] = b->a_off[pid] + (ca / 32u) * NP; sa_len[at] = ea - ca;
+                sb_off[at] = b->b_off[pid] + (cb / 32u) * NP; sb_len[at] = eb - cb;
+                longest = std::max(longest, std::min(ea - ca, eb - cb));
+                ca = ea; cb = eb;
+            }
+            for (uint32_t slot = 0; slot < SAMPLE_SLOTS; slot++) list[(size_t)SAMPLE_SLOTS * k + slot] = SAMPLE_SLOTS * k + slot;   // (slots beyond the parts: empty sequences)
         }
         n_sample = k;
         const uint32_t words = std::max(1u, (longest + 63u) / 64u);
@@ -849,7 +860,7 @@ int malcs_diag_setup(malcs_batch *b, int nlw, const std::vector<uint32_t> &pairs
     const size_t at_count = carve(keep, 2 * ncls);                         // two sets, used by alternate launches
     const size_t at_jbuf = carve(keep, (size_t)(cut_possible ? n_tiles : 1u) * 128u);   // one 64-bit word per lane of a cut tile
     const size_t at_stats = carve(keep, PS_FIELDS);
-    const size_t at_sample = carve(keep, (size_t)11 * n_sample + 64), at_sdist = carve(keep, 2 * (size_t)n_sample + 64);
+    const size_t at_sample = carve(keep, (size_t)(5 * SAMPLE_SLOTS + 1) * n_sample + 64), at_sdist = carve(keep, (size_t)SAMPLE_SLOTS * n_sample + 64);
     MALCS_HIP(malcs_pool_alloc(ctx, (void **)&d.d_rows, keep * sizeof(uint32_t)));
     (void)at_rows;                                                         // the rows come first: d_rows is the allocation
     uint32_t *const base = d.d_rows;
@@ -872,14 +883,14 @@ int malcs_diag_setup(malcs_batch *b, int nlw, const std::vector<uint32_t> &pairs
     }
     if (n_sample) {
         MALCS_HIP(malcs_h2d(st, d.d_sample, sample.data(), sample.size() * sizeof(uint32_t)));
-        const uint32_t two = 2u * n_sample;
-        MALCS_HIP(malcs_h2d(st, d.d_sample + (size_t)11 * n_sample, &two, sizeof(uint32_t)));
+        const uint32_t subs = SAMPLE_SLOTS * n_sample;
+        MALCS_HIP(malcs_h2d(st, d.d_sample + (size_t)(5 * SAMPLE_SLOTS + 1) * n_sample, &subs, sizeof(uint32_t)));
     }
     MALCS_HIP(malcs_sync(st));                                             // the sources are locals (copies beyond the staging buffer read them directly)
     d.nlw = nlw; d.T = malcs_diag_threshold(nlw); d.n_tiles = n_tiles; d.n_pairs = count; d.n_launch = n_launch;
     d.max_len = max_len; d.HB = HB; d.can_half = can_half; d.cut_possible = cut_possible; d.n_sample = n_sample;
     d.sample_W = sW; d.sample_L = sL; d.rows_cap = rows_cap; d.parity = 0; d.planned = false; d.plan_parity = 0;
-    d.sample_inside = n_sample && sW == 1 && sL > 1 && sL <= 32;                       // the sample as workgroups of the plan's first launch
+    d.sample_inside = n_sample && sW == 1 && sL > 1 && sL <= 64 / (int)SAMPLE_SLOTS;   // (the places of a pair in one wave)                       // the sample as workgroups of the plan's first launch
     return MALCS_OK;
 }
 
@@ -915,7 +926,7 @@ int malcs_diag_plan(malcs_batch *b)
     int logL = 0;
     while ((1 << logL) < d.sample_L) logL++;
     A.sample_logL = logL;
-    const uint32_t n2 = 2u * d.n_sample, ppw = 64u / (uint32_t)std::max(d.sample_L, 1);
+    const uint32_t n2 = SAMPLE_SLOTS * d.n_sample, ppw = 64u / (uint32_t)std::max(d.sample_L, 1);
     A.sample_blocks = d.sample_inside ? ((n2 + ppw - 1u) / ppw + 3u) / 4u : 0u;
     if (d.n_sample && !d.sample_inside) {
         // sub-pairs beyond 4 096 rows (sequences beyond 8 kb): the sample as a launch of its own, in front of the plan
@@ -936,7 +947,7 @@ int malcs_diag_plan(malcs_batch *b)
     case 4: hipLaunchKernelGGL((k_plan_ends<4, false>), g_ends, b256, hist_lds, st, A); break;
     }
     MALCS_HIP(hipGetLastError());
-    hipLaunchKernelGGL(k_plan_scatter, dim3((count + 1023u) / 1024u), dim3(1024), 3 * hist_lds, st, A);
+    hipLaunchKernelGGL(k_plan_scatter, dim3((count + 1023u) / 1024u + 1u), dim3(1024), 3 * hist_lds, st, A);   // (+ 1: the workgroup that publishes the plan)
     MALCS_HIP(hipGetLastError());
     // the first workgroup deals the pieces to the SIMDs, the others write the rows of a few places each
     int wpp = 4;
