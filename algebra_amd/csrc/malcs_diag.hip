@@ -950,16 +950,21 @@ int malcs_diag_plan(malcs_batch *b)
     hipLaunchKernelGGL(k_plan_scatter, dim3((count + 1023u) / 1024u + 1u), dim3(1024), 3 * hist_lds, st, A);   // (+ 1: the workgroup that publishes the plan)
     MALCS_HIP(hipGetLastError());
     // the first workgroup deals the pieces to the SIMDs, the others write the rows of a few places each
-    int wpp = 4;
-    if (const char *env = getenv("MALCS_LAYOUT_WPP")) wpp = atoi(env);     // dev: waves per place
-    const uint32_t places = 16u / (uint32_t)wpp;
+    int wpp = 4, bs = 512;
+    if (const char *env = getenv("MALCS_LAYOUT_WPP")) wpp = atoi(env);     // dev: waves per place, threads per workgroup
+    if (const char *env = getenv("MALCS_LAYOUT_BS")) bs = atoi(env);
+    if (NP != 2) { wpp = 4; bs = 1024; }
+    const uint32_t places = (uint32_t)(bs / 64 / wpp);
     const dim3 g_layout(1u + (d.n_launch + places - 1u) / places);
     const size_t layout_lds = ((size_t)std::max(2u * H2, RANK_BINS) + DEAL_MAX) * sizeof(uint32_t);
-#define LAYOUT(NPV, WPPV) hipLaunchKernelGGL((k_diag_layout<NPV, WPPV>), g_layout, dim3(1024), layout_lds, st, A)
+#define LAYOUT(NPV, WPPV, BSV) hipLaunchKernelGGL((k_diag_layout<NPV, WPPV, BSV>), g_layout, dim3(BSV), layout_lds, st, A)
     switch (NP) {
-    case 2: if (wpp == 1) LAYOUT(2, 1); else if (wpp == 2) LAYOUT(2, 2); else LAYOUT(2, 4); break;
-    case 3: LAYOUT(3, 4); break;
-    case 4: LAYOUT(4, 4); break;
+    case 2:
+        if (bs == 1024) { if (wpp == 8) LAYOUT(2, 8, 1024); else if (wpp == 2) LAYOUT(2, 2, 1024); else LAYOUT(2, 4, 1024); }
+        else            { if (wpp == 8) LAYOUT(2, 8, 512); else if (wpp == 2) LAYOUT(2, 2, 512); else LAYOUT(2, 4, 512); }
+        break;
+    case 3: LAYOUT(3, 4, 1024); break;
+    case 4: LAYOUT(4, 4, 1024); break;
     }
 #undef LAYOUT
     MALCS_HIP(hipGetLastError());

@@ -288,6 +288,42 @@ def test_edit_distance_two_limb_mode(native, half, monkeypatch):
     assert np.array_equal(got, O.edit_distance_batch(*data))
 
 
+@pytest.mark.parametrize("pairs,length,p,half", [(100000, 1000, 0.01, ""), (6000, 1000, 0.01, ""), (5000, 700, 0.04, ""), (7000, 460, 0.02, "1"),
+                                                 (3000, 1500, 0.01, "1"), (300000, 330, 0.02, "")])
+def test_window_plan_made_on_the_device(native, pairs, length, p, half, monkeypatch):
+    """The plan of the window class is made on the device and never comes back to the host for a launch (malcs_plan.inc);
+    read back through malcs_batch_plan_dump it must hold together: every pair of the class in one slot, slots sorted by
+    (group, blocks), the pieces of a tile cover its blocks, rows of different pieces do not overlap, the table of the
+    launch names every piece once -- after the first plan and after plans queued again behind launches -- and the
+    distances are the oracle's.  Sizes: all pieces dealt in LDS (cut, balanced and not), uncut three-limb tiles, more
+    tiles than the deal takes (the longest-first order)."""
+    from oracle import oracle as O
+    from util import check_window_plan
+    if half:
+        monkeypatch.setenv("MALCS_DIAG_HALF", half)
+    data = gen.c2_batch(pairs, seed=77, length=length, p=p)
+    batch = native.Batch(native.default_context(), *data, n_symbols=4)
+    first = check_window_plan(batch)
+    ref = O.edit_distance_batch(*data) if pairs <= 100000 else None
+    d0 = batch.distances()
+    for _ in range(3):
+        batch.replan()
+        batch.launch_distances()
+    again = check_window_plan(batch)
+    d1 = batch.fetch_distances()
+    batch.close()
+    assert first["pieces"] == again["pieces"] and first["rows"] == again["rows"]
+    assert np.array_equal(d0, d1)
+    if ref is not None:
+        assert np.array_equal(d0, ref)
+    else:
+        pick = np.random.RandomState(1).choice(pairs, 2000, replace=False)
+        syms, a_off, a_len, b_off, b_len = data
+        assert np.array_equal(d0[pick], O.edit_distance_batch(syms, a_off[pick], a_len[pick], b_off[pick], b_len[pick]))
+    if first.get("pieces", 0) <= 4096 and pairs >= 6000:
+        assert first["simd_load_max"] == first["reported_worst"]
+
+
 def test_empty_batch_and_bad_arguments(native):
     import algebra_amd
     assert algebra_amd.edit_distance_batch([]).tolist() == []
