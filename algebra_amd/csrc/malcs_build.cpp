@@ -578,6 +578,13 @@ static int gbuild_hook(void *user_, const malcs_sweep_chunk &c)
     // group how far the output has grown: while a group is being built, the words of the one before travel home on the
     // context's second stream (104 MB for 100 000 C2 graphs: 1.9 ms that used to follow the 2.5 ms of the kernels).
     if (!ctx->copy_stream) MALCS_HIP(hipStreamCreateWithFlags(&ctx->copy_stream, hipStreamNonBlocking));
+    // Whatever way this function is left, both streams are drained first: the pooled device blocks above go back to the
+    // context's pool when it returns, and the pool only promises that a block is handed out again behind work queued on
+    // the context's stream -- copies on the second stream (and their pinned targets) must be done by then.
+    struct drain {
+        hipStream_t a, b;
+        ~drain() { (void)hipStreamSynchronize(a); (void)hipStreamSynchronize(b); }
+    } drain_on_exit{st, ctx->copy_stream};
     struct group { size_t first, count; int kind; };
     std::vector<group> groups;
     {

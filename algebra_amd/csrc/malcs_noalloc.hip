@@ -85,10 +85,11 @@ k_na_scan(const uint64_t *__restrict__ a_off, const uint32_t *__restrict__ a_len
 // grid-stride over the blocks of the arena; the number of blocks is only known on the device
 template <int NP>
 __global__ void __launch_bounds__(256)
-k_na_pack(const uint8_t *__restrict__ syms, uint32_t n_seqs, uint32_t *__restrict__ sc)
+k_na_pack(const uint8_t *__restrict__ syms, uint32_t n_seqs, uint32_t n_symbols, uint32_t *__restrict__ sc)
 {
     const uint64_t *seq_byte_off = reinterpret_cast<const uint64_t *>(sc + AT_SEQ_BYTE_OFF);
-    const uint32_t *seq_len = sc + AT_SEQ_LEN, *seq_blk_off = sc + AT_SEQ_BLK_OFF;
+    uint32_t *seq_len = sc + AT_SEQ_LEN;
+    const uint32_t *seq_blk_off = sc + AT_SEQ_BLK_OFF;
     const uint32_t total = sc[AT_COUNTERS + 16];
     for (uint32_t blk = blockIdx.x * blockDim.x + threadIdx.x; blk < total; blk += gridDim.x * blockDim.x) {
         uint32_t lo = 0, hi = n_seqs;                                    // last s with seq_blk_off[s] <= blk
@@ -100,9 +101,18 @@ k_na_pack(const uint8_t *__restrict__ syms, uint32_t n_seqs, uint32_t *__restric
         if (len == 0xffffffffu) continue;                                // a sequence that straddles the end of the arena
         const uint32_t k = blk - seq_blk_off[lo];
         uint32_t out[NP];
-        malcs_dev::pack_block<NP>(syms + seq_byte_off[lo] + (uint64_t)k * 32u, min(32u, len - k * 32u), out);
+        const uint8_t *src = syms + seq_byte_off[lo] + (uint64_t)k * 32u;
+        const uint32_t cnt = min(32u, len - k * 32u);
+        const uint32_t seen = malcs_dev::pack_block<NP>(src, cnt, out);      // the OR of the block's codes: an upper bound of every one
 #pragma unroll
         for (int p = 0; p < NP; p++) sc[AT_PLANES + (size_t)blk * NP + p] = out[p];
+        if (seen >= n_symbols) {
+            // a code that is not below n_symbols (malcs_batch_create rejects the batch; here the pairs of the sequence get
+            // -1): beyond the bit planes it would alias another symbol and the distance would be silently wrong
+            uint32_t worst = 0;
+            for (uint32_t j = 0; j < cnt; j++) worst = max(worst, (uint32_t)src[j]);
+            if (worst >= n_symbols) seq_len[lo] = 0xffffffffu;           // (only ever set, read again by k_na_classify)
+        }
     }
 }
 
@@ -169,9 +179,9 @@ extern "C" int malcs_edit_distance_noalloc(malcs_ctx *ctx, void *stream, const u
     hipLaunchKernelGGL(k_na_scan, dim3(1), dim3(1024), 0, st, d_a_off, d_a_len, d_b_off, d_b_len, np32, n_syms, cap_blocks, sc);
     const dim3 pack_grid(2048), b256(256);
     switch (NP) {
-    case 2: hipLaunchKernelGGL(k_na_pack<2>, pack_grid, b256, 0, st, d_syms, 2u * np32, sc); break;
-    case 3: hipLaunchKernelGGL(k_na_pack<3>, pack_grid, b256, 0, st, d_syms, 2u * np32, sc); break;
-    case 4: hipLaunchKernelGGL(k_na_pack<4>, pack_grid, b256, 0, st, d_syms, 2u * np32, sc); break;
+    case 2: hipLaunchKernelGGL(k_na_pack<2>, pack_grid, b256, 0, st, d_syms, 2u * np32, (uint32_t)n_symbols, sc); break;
+    case 3: hipLaunchKernelGGL(k_na_pack<3>, pack_grid, b256, 0, st, d_syms, 2u * np32, (uint32_t)n_symbols, sc); break;
+    case 4: hipLaunchKernelGGL(k_na_pack<4>, pack_grid, b256, 0, st, d_syms, 2u * np32, (uint32_t)n_symbols, sc); break;
     }
     hipLaunchKernelGGL(k_na_classify, dim3((np32 + 255u) / 256u), b256, 0, st, np32, NP, sc, d_dist);
     MALCS_HIP(hipGetLastError());

@@ -143,7 +143,8 @@ int malcs_edit_distance_batch(malcs_ctx *ctx, const uint8_t *syms, uint64_t n_sy
  * file-scope device array of the library (14 MB per GPU, held until the process ends).  Limits, checked here:
  * n_pairs <= MALCS_NOALLOC_MAX_PAIRS, n_syms <= MALCS_NOALLOC_MAX_SYMS, 1 <= n_symbols <= 16 (else
  * MALCS_ERR_TOO_LONG / MALCS_ERR_ARG, nothing is enqueued).  Checked on the device, per pair (d_dist[i] = -1,
- * the other pairs are unaffected): a sequence outside [0, n_syms), a shorter sequence of more than
+ * the other pairs are unaffected): a sequence outside [0, n_syms), a sequence that holds a symbol code that is not
+ * below n_symbols (malcs_batch_create rejects such a batch as a whole), a shorter sequence of more than
  * MALCS_NOALLOC_MAX_LEN symbols, or packed sequences beyond the arena (the sum over all 2 n_pairs sequences of
  * ceil(len / 32) must not exceed MALCS_NOALLOC_PLANE_DWORDS / planes, planes = 2, 3, 4 for <= 4, 8, 16 symbols).
  * All calls on one GPU share that array: calls that overlap on one GPU (two streams, two threads) race. */
@@ -162,9 +163,11 @@ int malcs_edit_distance_noalloc(malcs_ctx *ctx, void *stream, const uint8_t *d_s
  * pair of the batch.  `shift` and `max_distance` may be NULL (all 0 / no limit; a max_distance
  * of 0 means no limit, as in the reference, :345).
  *
- * The device computes the distance and the optimal maximal match runs (row, col, length, level);
- * the host part of the library orders them as the reference's sweep does and compresses them
- * into the graph exactly as _build_graph does.  Results are held by the returned handle.
+ * The device computes the distance and the optimal maximal match runs (row, col, length, level),
+ * orders them as the reference's sweep does and compresses them into the graph exactly as _build_graph
+ * does (kernel family 2c: one source, malcs_graph_core.hpp, compiled for the device and for the host;
+ * the host half builds what the device builder does not take: graphs of the bit-vector paths and graphs
+ * beyond its run limit).  Results are held by the returned handle.
  *
  * Per pair i the handle exposes
  *   status     MALCS_PAIR_*                      distance   graph.distance

@@ -3,6 +3,8 @@ arithmetic and the tiled/sharded relation matrix.  Graph arrays come from the go
 from the CPU oracle (allowed in tests); distances for the matrix come from the oracle through the
 `distance_fn` hook.  The GPU versions of the same checks live in test_gpu_relations.py."""
 
+import time
+
 import numpy as np
 import pytest
 from util import HostTiles
@@ -170,3 +172,45 @@ def test_graph_batch_keeps_columns_only_while_it_holds_the_same_graphs():
     assert batch.columns("ACGA", make) == 5
     assert type(batch[1:3]) is list and type(batch + batch) is list and not hasattr(batch[1:3], "columns")
     assert GraphBatch().columns("", make) == 6
+
+
+def test_communicator_id_handshake_turns_strangers_away():
+    """algebra_amd.comm: rank 0 hands the communicator's id only to connections that say which rank of which job they are;
+    a stray connection and a rank of another job do not use up a place (they used to, and a real rank then waited for
+    its time limit)."""
+    import socket
+    import threading
+    from algebra_amd import comm
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    uid = bytes(range(128))
+    got, errors = {}, []
+
+    def serve():
+        try:
+            comm._serve(uid, "127.0.0.1", port, 3, 20, "job-a")
+        except Exception as e:                                  # noqa: BLE001
+            errors.append(e)
+
+    server = threading.Thread(target=serve)
+    server.start()
+    # a stranger that says nothing, and a rank of another job: both are turned away
+    deadline = time.time() + 10
+    while True:
+        try:
+            stray = socket.create_connection(("127.0.0.1", port), timeout=5)
+            break
+        except OSError:
+            assert time.time() < deadline
+            time.sleep(0.05)
+    stray.close()
+    with socket.create_connection(("127.0.0.1", port), timeout=5) as other:
+        other.sendall(comm._hello(1, 3, "job-b"))
+        other.settimeout(5)
+        assert other.recv(128) == b""
+    for rank in (2, 1):
+        got[rank] = comm._fetch("127.0.0.1", port, 10, rank, 3, "job-a")
+    server.join(20)
+    assert not server.is_alive() and not errors
+    assert got == {1: uid, 2: uid}

@@ -108,3 +108,39 @@ def test_noalloc_limits():
     data[3][2] = np.uint64(data[0].size)                       # pair 2: b starts at the end of the buffer and has symbols
     got = _noalloc(native, ctx, tuple(data), 4)
     assert got[0] == want[0] and got[1] == -1 and got[2] == -1
+
+
+def test_noalloc_bad_codes_full_arena_and_four_planes():
+    """A symbol code that is not below n_symbols marks the pairs of its sequence with -1 (malcs_batch_create rejects such
+    a batch as a whole); sequences beyond the packed arena likewise, the pairs in front of them exact; 9 to 16 symbols
+    (four planes) against the existing entry."""
+    from algebra_amd import _native as native
+    ctx = native.default_context()
+    rs = np.random.RandomState(79)
+    # four planes
+    wide = _pairs(rs, list(rs.randint(0, 900, 500)) + [3000, 4097], 13, indel=0.05)
+    assert np.array_equal(_noalloc(native, ctx, wide, 13), _existing(native, ctx, wide, 13))
+    # codes out of range: beyond n_symbols but inside the planes (5 of 0..7 with n_symbols = 5), and beyond the planes
+    data = list(_pairs(rs, [300, 400, 500, 600], 4))
+    want = _existing(native, ctx, tuple(data), 4)
+    syms = data[0].copy()
+    syms[int(data[1][1]) + 7] = 6                               # pair 1, sequence a: 6 >= n_symbols = 5 (three planes hold it)
+    syms[int(data[3][3]) + 100] = 9                             # pair 3, sequence b: beyond three planes
+    data[0] = syms
+    got = _noalloc(native, ctx, tuple(data), 5)
+    assert got[0] == want[0] and got[2] == want[2] and got[1] == -1 and got[3] == -1
+    # the packed arena (2 Mi dwords = 1 Mi blocks of 32 DNA symbols) is full after 2 x 16 pairs of 1 Mi symbols: the rest get -1
+    n, length = 1200, 1 << 15
+    a = rs.randint(0, 4, length).astype(np.uint8)
+    syms = np.concatenate([a, a[: length - 5]])
+    a_off = np.zeros(n, np.uint64); a_len = np.full(n, length, np.uint32)
+    b_off = np.full(n, length, np.uint64); b_len = np.full(n, length - 5, np.uint32)
+    a_len[0] = b_len[0] = 1000                                  # (a pair that any arena holds)
+    got = _noalloc(native, ctx, (syms, a_off, a_len, b_off, b_len), 4)
+    assert got[0] == 0                                           # prefixes of the same sequence
+    assert (got[1:] == -1).all()                                 # shorter side beyond 16 384 symbols: limit per pair (32 768 here)
+    short = 16000
+    a_len[:] = short; b_len[:] = short - 5
+    n_fit = (2 << 20) // 2 // (2 * ((short + 31) // 32))         # pairs whose blocks the arena holds
+    got = _noalloc(native, ctx, (syms, a_off, a_len, b_off, b_len), 4)
+    assert (got >= 0).all() if n <= n_fit else ((got[:n_fit] == 5).all() and (got[n_fit + 1:] == -1).all())
