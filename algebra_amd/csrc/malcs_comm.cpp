@@ -33,9 +33,11 @@ int load_rccl()
 {
     std::lock_guard<std::mutex> lock(g_rccl_mutex);
     if (g_rccl.lib) return MALCS_OK;
-    const char *names[] = {getenv("MALCS_RCCL_LIB"), "librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so"};
+    const char *named = getenv("MALCS_RCCL_LIB");                // set: that library or none (no quiet second choice)
+    const char *names[] = {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so"};
     void *lib = nullptr;
-    for (const char *name : names) if (name && *name && (lib = dlopen(name, RTLD_NOW | RTLD_GLOBAL))) break;
+    if (named && *named) lib = dlopen(named, RTLD_NOW | RTLD_GLOBAL);
+    else for (const char *name : names) if ((lib = dlopen(name, RTLD_NOW | RTLD_GLOBAL))) break;
     if (!lib) { malcs_set_error("librccl.so cannot be loaded (%s); set MALCS_RCCL_LIB", dlerror()); return MALCS_ERR_HIP; }
     rccl_api api;
     api.lib = lib;

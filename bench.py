@@ -263,6 +263,7 @@ def relation_matrix(ctx, gen, rank, world, comm, gather, fence, all_max):
             "per_variant_columns_s": round(t_columns, 4),
             "matrix_s_covers": "tiles + pre-filters, undecided pairs decided on the device, all-gather, assembly, the full matrix in (pinned) host memory; graphs and their per-variant columns are made before it",
             "matrix_s": round(seconds, 4), "label_histogram": np.bincount(labels.ravel(), minlength=5).tolist(),
+            "upper_histogram": np.bincount(labels[np.triu_indices(len(graphs), 1)], minlength=5).tolist(),
             "stages_ms_rank0": {k[8:]: round(v * 1e3 / reps, 2) for k, v in stats.items() if k.startswith("seconds_")}}
 
 
@@ -300,6 +301,8 @@ def main():
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl = RCCL; gloo only to rehearse the "
                                                       "multi-rank path on a box with fewer GPUs than ranks)")
     ap.add_argument("--share-device", action="store_true", help="rehearsal: all ranks use GPU 0")
+    ap.add_argument("--matrix-rccl", action="store_true", help="the relation matrix's all-gather through the library's RCCL "
+                                                               "communicator whatever --backend is (the default with nccl)")
     args = ap.parse_args()
 
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
@@ -453,14 +456,24 @@ def main():
         def run_matrix():
             try:
                 comm = gather = None
-                if world > 1 and args.backend == "nccl":
+                if world > 1 and (args.backend == "nccl" or args.matrix_rccl):
                     # the library's own RCCL communicator (no torch in that path); its 128-byte id travels over the
                     # process group this script has anyway
-                    uid = torch.zeros(128, dtype=torch.uint8, device="cuda")
+                    where = "cuda" if args.backend == "nccl" else "cpu"
+                    uid = torch.zeros(129, dtype=torch.uint8, device=where)    # 128 bytes of id + "rank 0 has one"
+                    failure = None
                     if rank == 0:
-                        uid.copy_(torch.frombuffer(bytearray(_native.comm_unique_id()), dtype=torch.uint8))
+                        try:
+                            uid.copy_(torch.frombuffer(bytearray(_native.comm_unique_id() + b"\x01"), dtype=torch.uint8))
+                        except Exception as e:                     # noqa: BLE001 -- the other ranks wait in the broadcast
+                            failure = e
                     dist.broadcast(uid, 0)
-                    comm = _native.Comm(ctx, bytes(uid.cpu().numpy().tobytes()), rank, world)
+                    if failure is not None:
+                        raise failure
+                    raw = bytes(uid.cpu().numpy().tobytes())
+                    if raw[128] != 1:
+                        raise RuntimeError("rank 0 could not make a communicator id")
+                    comm = _native.Comm(ctx, raw[:128], rank, world)
                 elif world > 1:
                     def gather(block):                             # rehearsal on one card: gloo carries the label blocks
                         send = torch.from_numpy(np.ascontiguousarray(block))
