@@ -42,7 +42,8 @@ def _load():
         "malcs_ctx_sync": (c.c_int, [vp]),
         "malcs_ctx_device_info": (c.c_int, [vp, c.c_char_p, c.c_int, P(c.c_int), P(c.c_int)]),
         "malcs_batch_create": (c.c_int, [vp, vp, u64, vp, vp, vp, vp, u64, c.c_int, P(vp)]),
-        "malcs_batch_destroy": (c.c_int, [vp]),
+"malcs_batch_create_packed": (c.c_int, [vp, vp, u64, c.c_int, vp, vp, vp, vp, u64, c.c_int, P(vp)]),
+                "malcs_batch_destroy": (c.c_int, [vp]),
         "malcs_batch_size": (u64, [vp]),
         "malcs_batch_replan": (c.c_int, [vp]),
         "malcs_edit_distance_launch": (c.c_int, [vp]),
@@ -218,6 +219,33 @@ class Batch:
         check(lib.malcs_batch_create(ctx.handle, ptr(syms), syms.size, ptr(a_off), ptr(a_len), ptr(b_off), ptr(b_len),
                                      n, int(n_symbols), ctypes.byref(self.handle)))
         _live["batch"].add(self)
+
+    @classmethod
+    def from_packed(cls, ctx, planes, a_off, a_len, b_off, b_len, n_planes, n_dwords=None):
+        """A batch from sequences that are bit planes already (malcs_batch_create_packed; include/malcs.h has the
+        arena's format).  `planes`: a uint32 array in host memory, or an int = a device address on the context's device
+        (then `n_dwords` says how long the arena is).  Offsets in dwords, lengths in symbols."""
+        self = cls.__new__(cls)
+        self.ctx = ctx
+        tables = [np.ascontiguousarray(t, dtype=np.uint32) for t in (a_off, a_len, b_off, b_len)]
+        n = len(tables[0])
+        if any(len(t) != n for t in tables):
+            raise ValueError("offset/length arrays differ in length")
+        on_device = isinstance(planes, int)
+        if on_device:
+            if n_dwords is None:
+                raise ValueError("a device arena needs n_dwords")
+            where = ctypes.c_void_p(planes)
+        else:
+            planes = np.ascontiguousarray(planes, dtype=np.uint32)
+            n_dwords = planes.size
+            where = ptr(planes)
+        self.n_pairs = n
+        self.handle = ctypes.c_void_p()
+        check(lib.malcs_batch_create_packed(ctx.handle, where, int(n_dwords), int(on_device), *[ptr(t) for t in tables],
+                                            n, int(n_planes), ctypes.byref(self.handle)))
+        _live["batch"].add(self)
+        return self
 
     def close(self):
         if self.handle:

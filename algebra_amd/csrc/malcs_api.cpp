@@ -579,6 +579,94 @@ int malcs_batch_create(malcs_ctx *ctx, const uint8_t *syms, uint64_t n_syms,
     return MALCS_OK;
 }
 
+int malcs_batch_create_packed(malcs_ctx *ctx, const uint32_t *planes, uint64_t n_dwords, int planes_on_device,
+                              const uint32_t *a_off, const uint32_t *a_len, const uint32_t *b_off, const uint32_t *b_len,
+                              uint64_t n_pairs, int n_planes, malcs_batch **out)
+{
+    if (!out) { malcs_set_error("batch is NULL"); return MALCS_ERR_ARG; }
+    *out = nullptr;
+    if (!ctx) { malcs_set_error("ctx is NULL"); return MALCS_ERR_ARG; }
+    if (n_pairs && (!a_off || !a_len || !b_off || !b_len)) { malcs_set_error("offset/length arrays are NULL"); return MALCS_ERR_ARG; }
+    if (n_dwords && !planes) { malcs_set_error("planes is NULL"); return MALCS_ERR_ARG; }
+    if (n_planes != 2 && n_planes != 3 && n_planes != 4 && n_planes != 8) { malcs_set_error("n_planes %d is not 2, 3, 4 or 8", n_planes); return MALCS_ERR_ARG; }
+    if (n_pairs >= 0x7fffffffull) { malcs_set_error("too many pairs in one batch"); return MALCS_ERR_ARG; }
+    if (n_dwords >= 0xffffffffull) { malcs_set_error("batch needs more than 16 GiB of packed planes; split it"); return MALCS_ERR_TOO_LONG; }
+    const uint32_t NP = (uint32_t)n_planes;
+    malcs_stage_trace trace("batch_create_packed");
+    uint32_t max_len = 0;
+    {
+        // every run of blocks inside the arena and at a block?  One pass without branches; the pair at fault is looked
+        // for only when there is one
+        uint64_t bad = 0;
+        uint32_t longest = 0;
+        auto run_bad = [&](uint64_t off, uint64_t len) -> uint64_t {
+            return (uint64_t)(off % NP != 0) | (uint64_t)(off + (len + 31u) / 32u * NP > n_dwords);
+        };
+        if (NP == 3) {
+            for (uint64_t i = 0; i < n_pairs; i++) {
+                bad |= run_bad(a_off[i], a_len[i]) | run_bad(b_off[i], b_len[i]);
+                longest = std::max(longest, std::max(a_len[i], b_len[i]));
+            }
+        } else {
+            const uint32_t low = NP - 1u, shift = NP == 2 ? 1u : NP == 4 ? 2u : 3u;
+            for (uint64_t i = 0; i < n_pairs; i++) {
+                const uint64_t ea = (uint64_t)a_off[i] + ((((uint64_t)a_len[i] + 31u) >> 5) << shift);
+                const uint64_t eb = (uint64_t)b_off[i] + ((((uint64_t)b_len[i] + 31u) >> 5) << shift);
+                bad |= (uint64_t)((a_off[i] | b_off[i]) & low) | (uint64_t)(ea > n_dwords) | (uint64_t)(eb > n_dwords);
+                longest = std::max(longest, std::max(a_len[i], b_len[i]));
+            }
+        }
+        max_len = longest;
+        for (uint64_t i = 0; bad && i < n_pairs; i++)
+            for (int side = 0; side < 2; side++) {
+                const uint64_t off = side ? b_off[i] : a_off[i], len = side ? b_len[i] : a_len[i];
+                if (!run_bad(off, len)) continue;
+                malcs_set_error("pair %llu: sequence of %llu symbols at dword %llu is not a run of whole blocks inside the arena of %llu dwords",
+                                (unsigned long long)i, (unsigned long long)len, (unsigned long long)off, (unsigned long long)n_dwords);
+                return MALCS_ERR_ARG;
+            }
+    }
+    malcs_batch *b = nullptr;
+    if (!ctx->spare_batches.empty()) { b = ctx->spare_batches.back(); ctx->spare_batches.pop_back(); }
+    else b = new (std::nothrow) malcs_batch();
+    if (!b) { malcs_set_error("out of host memory"); return MALCS_ERR_NOMEM; }
+    trace.lap("tables checked");
+    auto build = [&]() -> int {
+        b->ctx = ctx; b->n_pairs = n_pairs; b->n_planes = n_planes; b->max_len = max_len; b->arena_dwords = n_dwords;
+        b->a_off.assign(a_off, a_off + n_pairs); b->a_len.assign(a_len, a_len + n_pairs);
+        b->b_off.assign(b_off, b_off + n_pairs); b->b_len.assign(b_len, b_len + n_pairs);
+        MALCS_HIP(hipSetDevice(ctx->device));
+        hipStream_t st = ctx->stream;
+        if (n_pairs) {
+            MALCS_HIP(malcs_pool_alloc(ctx, (void **)&b->d_planes, (b->arena_dwords + 4) * sizeof(uint32_t)));
+            const size_t np = ((size_t)n_pairs + 63) & ~(size_t)63;
+            MALCS_HIP(malcs_pool_alloc(ctx, (void **)&b->d_pair_block, 6 * np * sizeof(uint32_t)));
+            b->d_a_off = b->d_pair_block; b->d_a_len = b->d_pair_block + np; b->d_b_off = b->d_pair_block + 2 * np;
+            b->d_b_len = b->d_pair_block + 3 * np; b->d_order = b->d_pair_block + 4 * np;
+            b->d_dist = reinterpret_cast<int32_t *>(b->d_pair_block + 5 * np);
+            if (n_dwords)                                        // the library's own copy: the caller's arena is free again on return
+                MALCS_HIP(hipMemcpyAsync(b->d_planes, planes, n_dwords * sizeof(uint32_t),
+                                         planes_on_device ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice, st));
+            MALCS_HIP(hipMemsetAsync(b->d_planes + n_dwords, 0, 4 * sizeof(uint32_t), st));
+            MALCS_HIP(malcs_h2d(st, b->d_a_off, b->a_off.data(), n_pairs * 4));
+            MALCS_HIP(malcs_h2d(st, b->d_a_len, b->a_len.data(), n_pairs * 4));
+            MALCS_HIP(malcs_h2d(st, b->d_b_off, b->b_off.data(), n_pairs * 4));
+            MALCS_HIP(malcs_h2d(st, b->d_b_len, b->b_len.data(), n_pairs * 4));
+            const int rc = malcs_clear_tails_launch(ctx, b->d_planes, b->d_a_off, b->d_a_len, b->d_b_off, b->d_b_len, (uint32_t)n_pairs, n_planes);
+            if (rc) return rc;
+            if (!planes_on_device) MALCS_HIP(malcs_sync(st));    // pageable host planes: the copy must be over before the caller has them back
+        }
+        trace.lap("allocations, copies queued");
+        const int rc = malcs_dist_plan(b);
+        trace.lap("distance plan");
+        return rc;
+    };
+    const int rc = build();
+    if (rc) { (void)hipStreamSynchronize(ctx->stream); batch_release(b); return rc; }
+    *out = b;
+    return MALCS_OK;
+}
+
 }  // extern "C"
 
 int malcs_batch_create_device(malcs_ctx *ctx, const uint8_t *d_syms, uint64_t n_syms,

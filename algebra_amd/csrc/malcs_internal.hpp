@@ -229,6 +229,8 @@ int malcs_noalloc_setup(malcs_ctx *c);
 int malcs_pack_launch(malcs_ctx *ctx, const uint8_t *d_syms, const uint64_t *d_seq_byte_off,
                       const uint32_t *d_seq_len, const uint32_t *d_seq_blk_off, uint32_t n_seqs,
                       uint32_t total_blocks, int n_planes, uint32_t *d_planes);
+int malcs_clear_tails_launch(malcs_ctx *ctx, uint32_t *d_planes, const uint32_t *d_a_off, const uint32_t *d_a_len,
+                             const uint32_t *d_b_off, const uint32_t *d_b_len, uint32_t n_pairs, int n_planes);
 
 // malcs_diag.hip
 // pairs[i] goes to the window class; retry_class[i] indexes `classes` (its full-matrix launch class)

@@ -51,3 +51,29 @@ int malcs_pack_launch(malcs_ctx *ctx, const uint8_t *d_syms, const uint64_t *d_s
     MALCS_HIP(hipGetLastError());
     return MALCS_OK;
 }
+
+// A caller's arena (malcs_batch_create_packed) may carry anything in the bits behind a sequence's last symbol; the
+// library's own packers leave zeros there and the kernels that compare whole blocks count on it.  One thread per pair
+// clears them in the library's copy (pairs that share a sequence write the same words with the same values).
+__global__ void k_clear_tails(uint32_t *planes, const uint32_t *a_off, const uint32_t *a_len, const uint32_t *b_off,
+                              const uint32_t *b_len, uint32_t n_pairs, int NP)
+{
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n_pairs) return;
+    for (int side = 0; side < 2; side++) {
+        const uint32_t off = side ? b_off[i] : a_off[i], len = side ? b_len[i] : a_len[i];
+        if ((len & 31u) == 0) continue;
+        const uint32_t keep = (1u << (len & 31u)) - 1u;
+        uint32_t *last = planes + off + (uint64_t)(len >> 5) * NP;
+        for (int p = 0; p < NP; p++) { const uint32_t w = last[p]; if (w & ~keep) last[p] = w & keep; }
+    }
+}
+
+int malcs_clear_tails_launch(malcs_ctx *ctx, uint32_t *d_planes, const uint32_t *d_a_off, const uint32_t *d_a_len,
+                             const uint32_t *d_b_off, const uint32_t *d_b_len, uint32_t n_pairs, int n_planes)
+{
+    if (n_pairs == 0) return MALCS_OK;
+    k_clear_tails<<<dim3((n_pairs + 255u) / 256u), dim3(256), 0, ctx->stream>>>(d_planes, d_a_off, d_a_len, d_b_off, d_b_len, n_pairs, n_planes);
+    MALCS_HIP(hipGetLastError());
+    return MALCS_OK;
+}

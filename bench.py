@@ -444,6 +444,25 @@ def main():
     e2e_s = (time.perf_counter() - t0) / reps
     assert np.array_equal(d_once, d)
 
+    # the same batches from sequences that are bit planes already (malcs_batch_create_packed): a caller that keeps its
+    # windows packed -- in host memory, or in HBM -- skips the pack of 100 MB of bytes per batch
+    from util import pack_arena
+    planes, where = pack_arena(syms, np.concatenate([a_off, b_off]), np.concatenate([a_len, b_len]), 2)
+    pa, pb = where[:args.pairs].copy(), where[args.pairs:].copy()
+    resident = torch.from_numpy(planes.view(np.int32)).cuda()
+    torch.cuda.synchronize()
+    packed_s = {}
+    for name_, arena, n_dw in (("host_planes", planes, None), ("device_planes", int(resident.data_ptr()), planes.size)):
+        for timed in (False, True):
+            t0 = time.perf_counter()
+            for _ in range(reps if timed else 1):
+                once = _native.Batch.from_packed(ctx, arena, pa, a_len, pb, b_len, 2, n_dwords=n_dw)
+                d_once = once.distances()
+                once.close()
+            packed_s[name_] = (time.perf_counter() - t0) / reps
+        assert np.array_equal(d_once, d)
+    del resident
+
     # the relation matrix is a job of all ranks (sharded tiles + all-gather): every rank takes part.  It runs beside the
     # headline, which is measured by now: a failure or a hang there (the RCCL path has only ever run on one card before
     # the driver's scaling run) is reported in the line instead of costing it.
@@ -547,6 +566,11 @@ def main():
             "end_to_end": {"pairs_per_s": round(args.pairs / e2e_s, 1), "ms": round(e2e_s * 1e3, 3),
                            "what": f"per batch, from {syms.nbytes / 1e6:.0f} MB of host bytes (pageable) to distances in host memory: "
                                    "create (pack on host cores, copy packed, plan) + launch + fetch + destroy"},
+            "end_to_end_packed": {
+                "what": "as end_to_end, but the caller's sequences are bit planes already (malcs_batch_create_packed, "
+                        f"{planes.nbytes / 1e6:.0f} MB): create (copy the planes, plan) + launch + fetch + destroy",
+                "from_host_planes": {"pairs_per_s": round(args.pairs / packed_s["host_planes"], 1), "ms": round(packed_s["host_planes"] * 1e3, 3)},
+                "from_device_planes": {"pairs_per_s": round(args.pairs / packed_s["device_planes"], 1), "ms": round(packed_s["device_planes"] * 1e3, 3)}},
         }
         if matrix is not None:
             out["relations_per_s"] = matrix["relations_per_s"]

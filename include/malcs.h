@@ -69,6 +69,24 @@ int malcs_batch_create(malcs_ctx *ctx, const uint8_t *syms, uint64_t n_syms,
                        const uint64_t *a_off, const uint32_t *a_len,
                        const uint64_t *b_off, const uint32_t *b_len,
                        uint64_t n_pairs, int n_symbols, malcs_batch **batch);
+/* The same batch from sequences that are ALREADY PACKED (a caller that keeps its reference / observed windows as bit
+ * planes -- on the host or, planes_on_device != 0, in HBM on the context's device -- skips the pack of the bytes; the
+ * reference has no such stage: edit_distance(a, b) takes str, algebra/lcs/edit_distance.py:21).
+ *
+ * The arena, `planes[n_dwords]`: a sequence of L symbols is a run of ceil(L / 32) BLOCKS; a block is `n_planes`
+ * consecutive dwords; bit j (least significant first) of dword p of block k is bit p of the code of symbol 32 k + j.
+ * n_planes = 2 for up to 4 symbols (DNA), 3 for up to 8, 4 for up to 16, 8 for up to 256.  Bits behind a sequence's last
+ * symbol may hold anything (the library clears them in its copy).  a_off[i] / b_off[i] = the dword at which the pair's
+ * reference / observed sequence begins (a multiple of n_planes; its whole run lies inside the arena); a_len / b_len in
+ * symbols.  Pairs may share sequences; an empty sequence may point anywhere inside the arena.  The four tables are host
+ * arrays.  The call copies the arena (it is the caller's again on return: a device-side arena must not be written by
+ * other streams before the context's stream has passed the copy -- malcs_ctx_sync) and plans the batch as
+ * malcs_batch_create does.  Errors: MALCS_ERR_ARG (n_planes, a run outside the arena or not block-aligned),
+ * MALCS_ERR_TOO_LONG (an arena of 2^32 - 1 dwords or more). */
+int malcs_batch_create_packed(malcs_ctx *ctx, const uint32_t *planes, uint64_t n_dwords, int planes_on_device,
+                              const uint32_t *a_off, const uint32_t *a_len,
+                              const uint32_t *b_off, const uint32_t *b_len,
+                              uint64_t n_pairs, int n_planes, malcs_batch **batch);
 int malcs_batch_destroy(malcs_batch *batch);
 uint64_t malcs_batch_size(const malcs_batch *batch);
 /* Queues the part of a batch's distance plan that depends on what its sequences hold, again, on the planes that are

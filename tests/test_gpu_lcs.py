@@ -324,6 +324,100 @@ def test_window_plan_made_on_the_device(native, pairs, length, p, half, monkeypa
         assert first["simd_load_max"] == first["reported_worst"]
 
 
+def _as_packed(native, args, n_planes, rs=None, on_device=False):
+    """The batch of byte sequences `args` = (syms, a_off, a_len, b_off, b_len) again through malcs_batch_create_packed, from
+    an arena this test packs with numpy (util.pack_arena: include/malcs.h's format restated)."""
+    from util import pack_arena
+    syms, a_off, a_len, b_off, b_len = args
+    n = len(a_len)
+    planes, where = pack_arena(syms, np.concatenate([a_off, b_off]), np.concatenate([a_len, b_len]), n_planes, junk_tails=rs)
+    ctx = native.default_context()
+    if not on_device:
+        return native.Batch.from_packed(ctx, planes, where[:n], a_len, where[n:], b_len, n_planes)
+    from util import hip_runtime, to_device
+    resident = to_device(planes)
+    try:
+        batch = native.Batch.from_packed(ctx, resident.value, where[:n], a_len, where[n:], b_len, n_planes, n_dwords=planes.size)
+        ctx.sync()                                                     # the library has its copy: the caller's arena may go
+    finally:
+        hip_runtime().hipFree(resident)
+    return batch
+
+
+@pytest.mark.parametrize("n_symbols,n_planes", [(4, 2), (7, 3), (13, 4), (200, 8)])
+def test_packed_batches_word_boundaries(native, n_symbols, n_planes):
+    """malcs_batch_create_packed: the caller's bit planes instead of bytes, junk behind every sequence's last symbol."""
+    from oracle import oracle as O
+    rs = np.random.RandomState(700 + n_symbols)
+    lengths = [0, 1, 31, 32, 33, 63, 64, 65, 127, 128, 129, 255, 256, 257, 511, 512, 513, 1000, 1023, 1024, 1025, 2049, 4097]
+    flat = []
+    for m in lengths:
+        a = rs.randint(0, n_symbols, m).astype(np.uint8)
+        keep = rs.random_sample(m) > 0.02
+        flat += [a, np.concatenate([a[keep], rs.randint(0, n_symbols, rs.randint(0, 4)).astype(np.uint8)])]
+        flat += [a, rs.randint(0, n_symbols, max(0, m + rs.randint(-2, 3))).astype(np.uint8)]
+    off = np.concatenate([[0], np.cumsum([len(x) for x in flat])]).astype(np.uint64)
+    lens = np.array([len(x) for x in flat], np.uint32)
+    syms = np.concatenate(flat + [np.zeros(1, np.uint8)])
+    args = (syms, off[0:-1:2], lens[0::2], off[1::2], lens[1::2])
+    want = O.edit_distance_batch(*args).tolist()
+    for on_device in (False, True):
+        batch = _as_packed(native, args, n_planes, rs, on_device)
+        assert batch.distances().tolist() == want
+        batch.replan()
+        batch.launch_distances()
+        assert batch.fetch_distances().tolist() == want
+        batch.close()
+
+
+def test_packed_batch_c2_and_graphs(native):
+    """The C2 workload from planes that are in HBM already: distances, plan invariants and LCS graphs are those of the
+    batch made from bytes; pairs that share a sequence share its blocks."""
+    from util import check_window_plan
+    data = gen.c2_batch(20000, seed=9)
+    ctx = native.default_context()
+    plain = native.Batch(ctx, *data, 4)
+    want = plain.distances()
+    packed = _as_packed(native, data, 2, np.random.RandomState(1), on_device=True)
+    assert np.array_equal(packed.distances(), want)
+    assert packed.plan_info() == plain.plan_info()
+    check_window_plan(packed)
+    plain.close(); packed.close()
+    # graphs, and pairs that share their reference window (one run of blocks, many pairs)
+    from util import pack_arena
+    small = gen.c2_batch(64, seed=10)
+    syms, a_off, a_len, b_off, b_len = small
+    planes, where = pack_arena(syms, np.concatenate([a_off[:1], b_off]), np.concatenate([a_len[:1], b_len]), 2)
+    shared = native.Batch.from_packed(ctx, planes, np.repeat(where[:1], 64), np.repeat(a_len[:1], 64), where[1:], b_len, 2)
+    plain = native.Batch(ctx, syms, np.repeat(a_off[:1], 64), np.repeat(a_len[:1], 64), b_off, b_len, 4)
+    assert np.array_equal(shared.distances(), plain.distances())
+    g1, g2 = shared.graphs(), plain.graphs()
+    assert np.array_equal(g1.counts, g2.counts)
+    for i in range(0, 64, 7):
+        assert np.array_equal(g1.nodes(i), g2.nodes(i)) and np.array_equal(g1.edges(i), g2.edges(i))
+    g1.close(); g2.close(); shared.close(); plain.close()
+
+
+def test_packed_batch_bad_arguments(native):
+    ctx = native.default_context()
+    planes = np.zeros(8, np.uint32)
+    with pytest.raises(native.MalcsError, match="n_planes"):
+        native.Batch.from_packed(ctx, planes, [0], [10], [2], [10], 5)
+    with pytest.raises(native.MalcsError, match="whole blocks inside the arena"):
+        native.Batch.from_packed(ctx, planes, [0], [10], [1], [10], 2)        # not at a block
+    with pytest.raises(native.MalcsError, match="whole blocks inside the arena"):
+        native.Batch.from_packed(ctx, planes, [0], [10], [6], [40], 2)        # runs past the end
+    ok = native.Batch.from_packed(ctx, planes, [0], [64], [4], [64], 2)       # 2 + 2 blocks: the arena exactly
+    assert ok.distances().tolist() == [0]
+    ok.close()
+    empty = native.Batch.from_packed(ctx, np.zeros(0, np.uint32), [], [], [], [], 2)
+    assert empty.distances().tolist() == []
+    empty.close()
+    lone = native.Batch.from_packed(ctx, planes, [0], [0], [0], [33], 2)      # an empty sequence against 33 symbols
+    assert lone.distances().tolist() == [33]
+    lone.close()
+
+
 def test_empty_batch_and_bad_arguments(native):
     import algebra_amd
     assert algebra_amd.edit_distance_batch([]).tolist() == []

@@ -34,26 +34,7 @@ def _existing(native, ctx, data, n_symbols):
     return out
 
 
-_hip = None
-
-
-def _runtime():
-    global _hip
-    if _hip is None:
-        from algebra_amd import _native  # noqa: F401  (loads libmalcs and with it the HIP runtime; the soname then resolves to that copy)
-        _hip = ctypes.CDLL("libamdhip64.so.7")
-        _hip.hipMalloc.argtypes = [ctypes.POINTER(ctypes.c_void_p), ctypes.c_size_t]
-        _hip.hipMemcpy.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_size_t, ctypes.c_int]
-        _hip.hipFree.argtypes = [ctypes.c_void_p]
-    return _hip
-
-
-def _to_device(array):
-    hip = _runtime()
-    p = ctypes.c_void_p()
-    assert hip.hipMalloc(ctypes.byref(p), max(array.nbytes, 4)) == 0
-    assert hip.hipMemcpy(p, array.ctypes.data_as(ctypes.c_void_p), array.nbytes, 1) == 0      # hipMemcpyHostToDevice
-    return p
+from util import hip_runtime as _runtime, to_device as _to_device  # noqa: E402
 
 
 def _noalloc(native, ctx, data, n_symbols):

@@ -223,3 +223,54 @@ def check_window_plan(batch):
     np.add.at(load, np.arange(L) % S, cost)
     return {"pieces": n_pieces, "tiles": n_tiles, "rows": spans[-1][1], "two_limb_tiles": info["two_limb_tiles"],
             "simd_load_max": int(load.max()), "simd_load_mean": float(load.mean()), "reported_worst": info["worst_simd"]}
+
+
+def pack_arena(syms, offs, lens, n_planes, junk_tails=None):
+    """The packed arena of include/malcs.h (malcs_batch_create_packed), made with numpy from the bytes: sequence s =
+    syms[offs[s] : offs[s] + lens[s]] becomes ceil(len / 32) blocks of `n_planes` dwords, bit j of dword p of block k =
+    bit p of symbol 32 k + j.  Returns (planes, dword offset of every sequence).  `junk_tails`: a RandomState that fills
+    the bits behind every sequence's last symbol (they may hold anything)."""
+    import numpy as np
+    syms = np.asarray(syms, dtype=np.uint8)
+    offs = np.asarray(offs, dtype=np.int64)
+    lens = np.asarray(lens, dtype=np.int64)
+    blocks = (lens + 31) // 32
+    first = np.concatenate([[0], np.cumsum(blocks)])                   # first block of every sequence
+    codes = np.zeros(int(first[-1]) * 32, dtype=np.uint8)
+    if junk_tails is not None:
+        codes[:] = junk_tails.randint(0, 1 << n_planes, size=codes.size)
+    seq_of = np.repeat(np.arange(len(lens)), lens)                     # for every symbol: its sequence
+    within = np.arange(int(lens.sum())) - np.repeat(np.cumsum(lens) - lens, lens)
+    codes[first[seq_of] * 32 + within] = syms[offs[seq_of] + within]
+    planes = np.empty((int(first[-1]), n_planes), dtype=np.uint32)
+    for p in range(n_planes):
+        bits = (codes >> p) & 1
+        planes[:, p] = np.packbits(bits, bitorder="little").view("<u4")
+    return planes.ravel(), (first[:-1] * n_planes).astype(np.uint32)
+
+
+_hip = None
+
+
+def hip_runtime():
+    """The HIP runtime libmalcs is linked against, through ctypes (hipMalloc / hipMemcpy / hipFree): device memory for a
+    test without a second framework initialising the GPU in this process."""
+    global _hip
+    if _hip is None:
+        import ctypes
+        from algebra_amd import _native  # noqa: F401  (loads libmalcs and with it the runtime; the soname then resolves to that copy)
+        _hip = ctypes.CDLL("libamdhip64.so.7")
+        _hip.hipMalloc.argtypes = [ctypes.POINTER(ctypes.c_void_p), ctypes.c_size_t]
+        _hip.hipMemcpy.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_size_t, ctypes.c_int]
+        _hip.hipFree.argtypes = [ctypes.c_void_p]
+    return _hip
+
+
+def to_device(array):
+    """A copy of the numpy array in device memory: a ctypes.c_void_p the caller frees with hip_runtime().hipFree."""
+    import ctypes
+    hip = hip_runtime()
+    p = ctypes.c_void_p()
+    assert hip.hipMalloc(ctypes.byref(p), max(array.nbytes, 4)) == 0
+    assert hip.hipMemcpy(p, array.ctypes.data_as(ctypes.c_void_p), array.nbytes, 1) == 0      # hipMemcpyHostToDevice
+    return p
