@@ -103,30 +103,38 @@ class LCSgraph:
         return result.canonical(index)
 
     @classmethod
-    def batch(cls, pairs, shifts=None, max_distances=None, ctx=None, devices=None):
+    def batch(cls, pairs, shifts=None, max_distances=None, ctx=None, devices=None, raise_on_limit=True):
         """`[LCSgraph(reference, observed, shift, max_distance), ...]` in one device batch, or, with `devices`
         (a list of device ids; default MALCS_DEVICES when set), dealt over one context per entry.
 
         Raises ValueError("maximum distance exceeded") if any pair exceeds its limit
-        (reference lcs_graph.py:345-346)."""
+        (reference lcs_graph.py:345-346) -- one pair's limit then costs the caller the whole batch, which the
+        reference's one-graph-per-call constructor never does.  `raise_on_limit=False` instead: the list holds None
+        where the constructor would have raised, and its `.status` (numpy uint8, one per pair: _native.PAIR_OK /
+        _native.PAIR_MAX_DISTANCE_EXCEEDED) says which."""
         pairs = list(pairs)
         n = len(pairs)
         if n == 0:
-            return []
+            out = GraphBatch()
+            out.status = np.zeros(0, dtype=np.uint8)
+            return out
         shift = np.zeros(n, dtype=np.int64) if shifts is None else np.asarray(list(shifts), dtype=np.int64)
         limit = None
         if max_distances is not None:
             limit = np.array([int(x) if x else 0 for x in max_distances], dtype=np.int64)
         contexts = _native.contexts_for(devices) if ctx is None else None
         if contexts and len(contexts) > 1 and n > 1:
-            out = [None] * n
+            out = GraphBatch([None] * n)
+            out.status = np.zeros(n, dtype=np.uint8)
 
             def part(job):
                 context, index = job
                 index = index.tolist()
                 if not index:
                     return
-                built = cls.batch([pairs[i] for i in index], shift[index], None if limit is None else limit[index], ctx=context)
+                built = cls.batch([pairs[i] for i in index], shift[index], None if limit is None else limit[index], ctx=context,
+                                  raise_on_limit=raise_on_limit)
+                out.status[index] = built.status
                 for i, graph in zip(index, built):
                     out[i] = graph
             _native.run_on_devices(part, list(zip(contexts, deal(pairs, len(contexts)))))
@@ -138,19 +146,27 @@ class LCSgraph:
             if n < 2:
                 raise
             half = n // 2
-            return (cls.batch(pairs[:half], shift[:half], None if limit is None else limit[:half], ctx=ctx) +
-                    cls.batch(pairs[half:], shift[half:], None if limit is None else limit[half:], ctx=ctx))
+            lo = cls.batch(pairs[:half], shift[:half], None if limit is None else limit[:half], ctx=ctx, raise_on_limit=raise_on_limit)
+            hi = cls.batch(pairs[half:], shift[half:], None if limit is None else limit[half:], ctx=ctx, raise_on_limit=raise_on_limit)
+            out = GraphBatch(list(lo) + list(hi))
+            out.status = np.concatenate([lo.status, hi.status])
+            return out
         batch = _native.Batch(ctx, syms, a_off, a_len, b_off, b_len, n_symbols)
         try:
             res = batch.graphs(shift, limit)
         finally:
             batch.close()
-        if np.any(res.status == _native.PAIR_MAX_DISTANCE_EXCEEDED):
+        status = np.asarray(res.status, dtype=np.uint8).copy()
+        beyond = status == _native.PAIR_MAX_DISTANCE_EXCEEDED
+        if raise_on_limit and np.any(beyond):
             res.close()
             raise ValueError("maximum distance exceeded")
         # the graphs share the result handle; it is released when the last of them goes away
         distance, supremal = res.distance.tolist(), res.supremal.tolist()      # Python ints once, not per graph
-        return GraphBatch(cls._from_arrays(pairs[i][1], distance[i], supremal[i], result=(res, i)) for i in range(n))
+        skip = beyond.tolist()
+        out = GraphBatch(None if skip[i] else cls._from_arrays(pairs[i][1], distance[i], supremal[i], result=(res, i)) for i in range(n))
+        out.status = status
+        return out
 
     @classmethod
     def from_sequence(cls, reference, observed):
@@ -390,7 +406,7 @@ class GraphBatch(list):
     graphs are single objects); every list operation works, and the kept columns are dropped as soon as the list no
     longer holds the graphs they were made from."""
 
-    __slots__ = ("_columns",)
+    __slots__ = ("_columns", "status")
 
     def columns(self, reference, make):
         kept = getattr(self, "_columns", None)

@@ -633,6 +633,27 @@ def test_max_distance(native):
             assert LCSgraph(a, b, max_distance=md).distance == rec["distance"]
 
 
+def test_max_distance_per_pair_status(native):
+    """All the reference's max_distance cases as ONE batch: raise_on_limit=False reports the pairs beyond their limit
+    one by one (None + status) instead of losing the batch to the first of them."""
+    from algebra_amd.lcs import LCSgraph
+    recs = REF["max_distance"] + SMALL["max_distance"]
+    assert any("error" in r for r in recs) and any("error" not in r for r in recs)
+    pairs = [(r["reference"], r["observed"]) for r in recs]
+    limits = [r["max_distance"] for r in recs]
+    with pytest.raises(ValueError, match="maximum distance exceeded"):
+        LCSgraph.batch(pairs, max_distances=limits)
+    graphs = LCSgraph.batch(pairs, max_distances=limits, raise_on_limit=False)
+    assert len(graphs) == len(recs)
+    for rec, graph, status in zip(recs, graphs, graphs.status.tolist()):
+        if "error" in rec:
+            assert graph is None and status == native.PAIR_MAX_DISTANCE_EXCEEDED
+        else:
+            assert status == native.PAIR_OK and graph.distance == rec["distance"]
+            assert graph.supremal == LCSgraph(rec["reference"], rec["observed"]).supremal
+    assert LCSgraph.batch([], raise_on_limit=False).status.tolist() == []
+
+
 def test_from_sequence(native):
     from algebra_amd.lcs import LCSgraph
     for rec in REF["sequences"] + SEQS["sequences"]:
