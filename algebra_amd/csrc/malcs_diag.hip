@@ -855,7 +855,7 @@ int malcs_diag_setup(malcs_batch *b, int nlw, const std::vector<uint32_t> &pairs
     const size_t at_pairs = carve(keep, count), at_cls = carve(keep, (count + 3) / 4), at_item = carve(keep, (size_t)ITEM_STRIDE * count);
     const size_t at_sets = carve(keep, 2 * (size_t)set_words);
     const size_t at_sitem = carve(keep, (size_t)ITEM_STRIDE * n_tiles * 64), at_pub = carve(keep, PUB_HDR_WORDS + 4 * (size_t)HB);
-    const size_t at_tab = carve(keep, (size_t)6 * n_launch + 4);
+    const size_t at_tab = carve(keep, (size_t)7 * n_launch + 4);
     const size_t at_list = carve(keep, std::max<uint32_t>(acc, 1)), at_first = carve(keep, ncls), at_cap = carve(keep, ncls);
     const size_t at_count = carve(keep, 2 * ncls);                         // two sets, used by alternate launches
     const size_t at_jbuf = carve(keep, (size_t)(cut_possible ? n_tiles : 1u) * 128u);   // one 64-bit word per lane of a cut tile
@@ -867,7 +867,7 @@ int malcs_diag_setup(malcs_batch *b, int nlw, const std::vector<uint32_t> &pairs
     d.d_pairs = base + at_pairs; d.d_cls = reinterpret_cast<uint8_t *>(base + at_cls); d.d_item = base + at_item;
     d.d_sets = base + at_sets; d.set_words = set_words; d.d_sitem = base + at_sitem; d.d_pub = base + at_pub;
     d.d_piece_off = base + at_tab; d.d_piece_info = d.d_piece_off + n_launch + 1; d.d_piece_join = d.d_piece_info + n_launch;
-    d.d_piece_place = d.d_piece_join + n_launch; d.d_lay_off = d.d_piece_place + n_launch; d.d_lay_info = d.d_lay_off + n_launch;
+    d.d_piece_place = d.d_piece_join + n_launch; d.d_lay_off = d.d_piece_place + n_launch; d.d_lay_info = d.d_lay_off + n_launch; d.d_lay_it = d.d_lay_info + n_launch;
     d.d_join_buf = base + at_jbuf; d.d_stats = base + at_stats;
     d.d_retry_list = base + at_list; d.d_retry_first = base + at_first; d.d_retry_cap = base + at_cap; d.d_retry_count = base + at_count;
     d.d_sample = base + at_sample; d.d_sample_dist = reinterpret_cast<int32_t *>(base + at_sdist);
@@ -906,7 +906,7 @@ int malcs_diag_plan(malcs_batch *b)
     A.pairs = d.d_pairs; A.cls = d.d_cls; A.item = d.d_item; A.sets = d.d_sets; A.set_words = d.set_words;
     d.plan_parity ^= 1u;
     A.parity = d.plan_parity;
-    A.sitem = d.d_sitem; A.pub = d.d_pub; A.lay_off = d.d_lay_off; A.lay_info = d.d_lay_info; A.piece_off = d.d_piece_off; A.piece_info = d.d_piece_info;
+    A.sitem = d.d_sitem; A.pub = d.d_pub; A.lay_off = d.d_lay_off; A.lay_info = d.d_lay_info; A.lay_it = d.d_lay_it; A.piece_off = d.d_piece_off; A.piece_info = d.d_piece_info;
     A.piece_join = d.d_piece_join; A.piece_place = d.d_piece_place; A.retry_count = d.d_retry_count; A.stats = d.d_stats; A.rows = d.d_rows;
     A.sample = d.d_sample; A.sample_dist = d.d_sample_dist;
     A.HB = HB; A.count = count; A.n_tiles = d.n_tiles; A.n_launch = d.n_launch; A.S = (uint32_t)std::max(1, ctx->prop.multiProcessorCount) * 4u;
@@ -949,24 +949,14 @@ int malcs_diag_plan(malcs_batch *b)
     MALCS_HIP(hipGetLastError());
     hipLaunchKernelGGL(k_plan_scatter, dim3((count + 1023u) / 1024u + 1u), dim3(1024), 3 * hist_lds, st, A);   // (+ 1: the workgroup that publishes the plan)
     MALCS_HIP(hipGetLastError());
-    // the first workgroup deals the pieces to the SIMDs, the others write the rows of a few places each
-    int wpp = 4, bs = 512;
-    if (const char *env = getenv("MALCS_LAYOUT_WPP")) wpp = atoi(env);     // dev: waves per place, threads per workgroup
-    if (const char *env = getenv("MALCS_LAYOUT_BS")) bs = atoi(env);
-    if (NP != 2) { wpp = 4; bs = 1024; }
-    const uint32_t places = (uint32_t)(bs / 64 / wpp);
-    const dim3 g_layout(1u + (d.n_launch + places - 1u) / places);
-    const size_t layout_lds = ((size_t)std::max(2u * H2, RANK_BINS) + DEAL_MAX) * sizeof(uint32_t);
-#define LAYOUT(NPV, WPPV, BSV) hipLaunchKernelGGL((k_diag_layout<NPV, WPPV, BSV>), g_layout, dim3(BSV), layout_lds, st, A)
+    // the first workgroup deals the pieces to the SIMDs, the others write the rows of two places each
+    const dim3 g_layout(1u + (d.n_launch + 1u) / 2u);
+    const size_t layout_lds = layout_lds_words(NP, 2u) * sizeof(uint32_t);
     switch (NP) {
-    case 2:
-        if (bs == 1024) { if (wpp == 8) LAYOUT(2, 8, 1024); else if (wpp == 2) LAYOUT(2, 2, 1024); else LAYOUT(2, 4, 1024); }
-        else            { if (wpp == 8) LAYOUT(2, 8, 512); else if (wpp == 2) LAYOUT(2, 2, 512); else LAYOUT(2, 4, 512); }
-        break;
-    case 3: LAYOUT(3, 4, 1024); break;
-    case 4: LAYOUT(4, 4, 1024); break;
+    case 2: hipLaunchKernelGGL((k_diag_layout<2, 512>), g_layout, dim3(512), layout_lds, st, A); break;
+    case 3: hipLaunchKernelGGL((k_diag_layout<3, 512>), g_layout, dim3(512), layout_lds, st, A); break;
+    case 4: hipLaunchKernelGGL((k_diag_layout<4, 512>), g_layout, dim3(512), layout_lds, st, A); break;
     }
-#undef LAYOUT
     MALCS_HIP(hipGetLastError());
     d.parity = 0;                                                          // the deal has zeroed both sets of retry counters
     d.planned = true;

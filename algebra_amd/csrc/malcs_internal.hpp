@@ -173,7 +173,7 @@ struct diag_plan {
     uint8_t *d_cls = nullptr;            // static: their retry class
     uint32_t *d_item = nullptr, *d_sitem = nullptr, *d_pub = nullptr, *d_sets = nullptr;   // item records by pair / by slot; the published plan;   // sets: two of { histogram, cursors, column sums }, used by alternate plans
     uint32_t set_words = 0, plan_parity = 0;
-    uint32_t *d_lay_off = nullptr, *d_lay_info = nullptr;   // the pieces in the order of the tiles: first row, column blocks | mode flags (0 = no piece)
+    uint32_t *d_lay_off = nullptr, *d_lay_info = nullptr, *d_lay_it = nullptr;   // the pieces in the order of the tiles: first row, column blocks | mode flags (0 = no piece)
     uint32_t *d_piece_off = nullptr;     // the same in the order of the launch's workgroups: first row of each piece
     uint32_t *d_piece_info = nullptr;    // column blocks of each piece | mode flags; 0 = no piece
     uint32_t *d_piece_join = nullptr;    // for the pieces of a cut tile: which slot of the join buffer they meet in
