@@ -71,6 +71,14 @@ def _load():
         "malcs_graphs_timing": (c.c_int, [vp, vp]),
         "malcs_graphs_device_built": (c.c_int, [vp, P(u64), P(c.c_float)]),
         "malcs_graphs_tie_bytes": (c.c_int, [vp, P(u64), P(u64)]),
+        "malcs_from_variant_batch": (c.c_int, [vp, vp, u64, u64, vp, vp, vp, vp, i64, c.c_int, P(vp)]),
+        "malcs_vgraphs_destroy": (c.c_int, [vp]),
+        "malcs_vgraphs_size": (u64, [vp]),
+        "malcs_vgraphs_columns": (c.c_int, [vp, vp, vp, vp, vp]),
+        "malcs_vgraphs_observed": (c.c_int, [vp, vp]),
+        "malcs_vgraphs_rounds": (c.c_int, [vp, P(c.c_int)]),
+        "malcs_vgraphs_round": (c.c_int, [vp, c.c_int, P(vp), P(u64)]),
+        "malcs_vgraphs_matrix_columns": (c.c_int, [vp, vp, vp, P(c.c_int), vp, vp, vp, vp]),
         "malcs_relmatrix_create": (c.c_int, [vp, u64, vp, vp, vp, vp, u32, u32, u32, P(vp)]),
         "malcs_relmatrix_destroy": (c.c_int, [vp]),
         "malcs_relmatrix_pending_count": (c.c_int, [vp, P(u64)]),
@@ -328,9 +336,10 @@ class Batch:
 class Graphs:
     """Result handle of malcs_lcs_graph_batch, read out into numpy arrays."""
 
-    def __init__(self, handle, n_pairs):
+    def __init__(self, handle, n_pairs, owner=None):
         self.handle = handle
         self.n_pairs = n_pairs
+        self.owner = owner                       # set: the handle belongs to that object (a round of VariantGraphs) and lives with it
         _live["graphs"].add(self)
         try:
             # large handles read their columns into recycled pinned blocks: pages that exist already (fresh numpy
@@ -384,7 +393,78 @@ class Graphs:
 
     def close(self):
         if self.handle:
-            lib.malcs_graphs_destroy(self.handle)
+            if self.owner is None:
+                lib.malcs_graphs_destroy(self.handle)
+            self.handle = ctypes.c_void_p()
+            self.owner = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+class VariantGraphs:
+    """Result handle of malcs_from_variant_batch: the supremal LCS graphs of n alleles of one reference, as arrays."""
+
+    def __init__(self, ctx, ref, start, end, ins, ins_off, offset, n_symbols):
+        ref = np.ascontiguousarray(ref, dtype=np.uint8)
+        start = np.ascontiguousarray(start, dtype=np.int64)
+        end = np.ascontiguousarray(end, dtype=np.int64)
+        ins = np.ascontiguousarray(ins, dtype=np.uint8)
+        ins_off = np.ascontiguousarray(ins_off, dtype=np.uint64)
+        n = len(start)
+        if len(end) != n or len(ins_off) != n + 1:
+            raise ValueError("start / end / ins_off differ in length")
+        self.n = n
+        self.handle = ctypes.c_void_p()
+        self._rounds = {}
+        check(lib.malcs_from_variant_batch(ctx.handle, ptr(ref), ref.size, n, ptr(start), ptr(end), ptr(ins), ptr(ins_off), int(offset),
+                                           int(n_symbols), ctypes.byref(self.handle)))
+        _live["graphs"].add(self)
+        self.where = np.empty((n, 4), dtype=np.int64)
+        self.distance = np.empty(n, dtype=np.int64)
+        self.supremal = np.empty((n, 4), dtype=np.int64)
+        self.obs_off = np.empty(n + 1, dtype=np.uint64)
+        check(lib.malcs_vgraphs_columns(self.handle, ptr(self.where), ptr(self.distance), ptr(self.supremal), ptr(self.obs_off)))
+        self.observed = np.empty(int(self.obs_off[-1]) + 1, dtype=np.uint8)
+        check(lib.malcs_vgraphs_observed(self.handle, ptr(self.observed)))
+        count = ctypes.c_int()
+        check(lib.malcs_vgraphs_rounds(self.handle, ctypes.byref(count)))
+        self.n_rounds = count.value
+
+    def round(self, r):
+        """The Graphs handle of widening round r (nodes / edges / canonical of the graphs that ended there)."""
+        made = self._rounds.get(r)
+        if made is None:
+            handle, size = ctypes.c_void_p(), ctypes.c_uint64()
+            check(lib.malcs_vgraphs_round(self.handle, int(r), ctypes.byref(handle), ctypes.byref(size)))
+            made = self._rounds[r] = Graphs(handle, size.value, owner=self)
+        return made
+
+    def matrix_columns(self, with_atoms):
+        """key, symmask, folded, sup_off, sup, atom_off, atoms (malcs_vgraphs_matrix_columns)."""
+        n = self.n
+        key = np.empty(n, dtype=np.uint32)
+        symmask = np.empty(n, dtype=np.uint64)
+        sup_off = np.zeros(n + 1, dtype=np.uint64)
+        np.cumsum(self.supremal[:, 3] - self.supremal[:, 2], out=sup_off[1:])
+        sup = np.empty(int(sup_off[-1]) + 1, dtype=np.uint8)
+        atom_off = np.zeros(n + 1, dtype=np.uint64)
+        np.cumsum(self.supremal[:, 1] - self.supremal[:, 0] + 1, out=atom_off[1:])
+        atoms = np.zeros(int(atom_off[-1]), dtype=np.uint8) if with_atoms else None
+        folded = ctypes.c_int()
+        check(lib.malcs_vgraphs_matrix_columns(self.handle, ptr(key), ptr(symmask), ctypes.byref(folded), ptr(sup_off), ptr(sup),
+                                               ptr(atom_off), ptr(atoms) if with_atoms else None))
+        return key, symmask, bool(folded.value), sup_off, sup[:-1], atom_off, atoms
+
+    def close(self):
+        if self.handle:
+            for made in self._rounds.values():
+                made.close()
+            self._rounds = {}
+            lib.malcs_vgraphs_destroy(self.handle)
             self.handle = ctypes.c_void_p()
 
     def __del__(self):

@@ -10,6 +10,7 @@ of one.
 """
 
 from collections import deque
+from collections.abc import MutableSequence
 
 import numpy as np
 
@@ -221,6 +222,10 @@ class LCSgraph:
         """`[from_variant(reference, allele, offset) for allele in alleles]` with the windows of every
         widening round built in one device batch (reference lcs_graph.py:113-123 runs the rounds per
         allele; alleles are independent, so the rounds can be shared)."""
+        alleles = list(alleles)
+        made = VariantGraphBatch.build(cls, reference, alleles, offset, ctx)
+        if made is not None:
+            return made
         return cls._from_alleles_batch([(reference, variants) for variants in alleles], offset, ctx)
 
     @classmethod
@@ -415,6 +420,122 @@ class GraphBatch(list):
             kept = (tuple(self), reference, make(reference, self))
             self._columns = kept
         return kept[2]
+
+
+_DNA_CODES = np.full(256, 255, dtype=np.uint8)
+_DNA_CODES[[ord(ch) for ch in "ACGT"]] = np.arange(4, dtype=np.uint8)
+
+
+class VariantGraphBatch(MutableSequence):
+    """What `from_variant_batch` returns when the library ran the widening rounds itself (malcs_from_variant_batch):
+    the graphs of all alleles as the library's arrays.  It reads like the list of `LCSgraph`s it stands for (length,
+    indexing, slices, iteration; a graph object is made when somebody asks for it), and the relation matrix takes its
+    per-variant columns straight from the library (`columns`), so 5 000 variants cost neither 5 000 window strings nor
+    5 000 objects.  Changing it (assignment, del, insert, ...) turns it into the `GraphBatch` of its graphs first, which
+    then does everything.  No counterpart in the reference (its graphs are single objects)."""
+
+    @classmethod
+    def build(cls, graph_cls, reference, alleles, offset, ctx):
+        """None when the library's entry does not apply: symbols beyond Latin-1 or more than 256 of them."""
+        try:
+            ref_raw = np.frombuffer(reference.encode("latin-1"), dtype=np.uint8)
+        except UnicodeEncodeError:
+            return None
+        starts, ends, seqs = [], [], []
+        for variants in alleles:
+            if not variants:                                    # no variant: the allele changes nothing
+                starts.append(0); ends.append(0); seqs.append("")
+            elif len(variants) == 1:
+                v = variants[0]
+                starts.append(v.start); ends.append(v.end); seqs.append(v.sequence)
+            else:                                               # several: the stretch they span, patched (reference lcs_graph.py:95-100)
+                start = min(v.start for v in variants)
+                end = max(v.end for v in variants)
+                starts.append(start); ends.append(end)
+                seqs.append(patch(reference[start:end], [Variant(v.start - start, v.end - start, v.sequence) for v in variants]))
+        try:
+            ins_raw = np.frombuffer("".join(seqs).encode("latin-1"), dtype=np.uint8)
+        except UnicodeEncodeError:
+            return None
+        ins_off = np.zeros(len(seqs) + 1, dtype=np.uint64)
+        np.cumsum(np.fromiter((len(x) for x in seqs), dtype=np.uint64, count=len(seqs)), out=ins_off[1:])
+        if len(ins_raw) != int(ins_off[-1]):
+            return None
+        present = np.zeros(256, dtype=bool)
+        present[ref_raw] = True
+        present[ins_raw] = True
+        symbols = np.nonzero(present)[0]
+        dna = bool(np.all(_DNA_CODES[symbols] < 4))
+        if dna:
+            table, n_symbols = _DNA_CODES, 4
+        else:
+            table = np.zeros(256, dtype=np.uint8)
+            table[symbols] = np.arange(len(symbols), dtype=np.uint8)
+            n_symbols = max(len(symbols), 1)
+        back = np.zeros(256, dtype=np.uint8)
+        back[table[symbols]] = symbols
+        ctx = ctx or _native.default_context()
+        ref_codes = table[ref_raw]
+        native = _native.VariantGraphs(ctx, ref_codes, starts, ends, table[ins_raw], ins_off, offset, n_symbols)
+        self = cls()
+        self._graph_cls, self._native, self._reference, self._ref_codes, self._back, self._dna = graph_cls, native, reference, ref_codes, back, dna
+        self._made = [None] * native.n
+        self._columns = None
+        self._list = None
+        return self
+
+    def __len__(self):
+        return self._native.n if self._list is None else len(self._list)
+
+    def _graph(self, i):
+        made = self._made[i]
+        if made is None:
+            nat = self._native
+            observed = self._back[nat.observed[int(nat.obs_off[i]):int(nat.obs_off[i + 1])]].tobytes().decode("latin-1")
+            made = self._made[i] = self._graph_cls._from_arrays(observed, nat.distance[i], nat.supremal[i].tolist(),
+                                                                result=(nat.round(int(nat.where[i, 0])), int(nat.where[i, 1])))
+        return made
+
+    def __getitem__(self, i):
+        if self._list is not None:
+            return self._list[i]
+        if isinstance(i, slice):
+            return [self._graph(k) for k in range(*i.indices(len(self)))]
+        if i < 0:
+            i += len(self)
+        if not 0 <= i < len(self):
+            raise IndexError("graph index out of range")
+        return self._graph(i)
+
+    def _as_list(self):
+        if self._list is None:
+            self._list = GraphBatch(self._graph(k) for k in range(self._native.n))
+            self._columns = None
+        return self._list
+
+    def __setitem__(self, i, graph):
+        self._as_list()[i] = graph
+
+    def __delitem__(self, i):
+        del self._as_list()[i]
+
+    def insert(self, i, graph):
+        self._as_list().insert(i, graph)
+
+    def __eq__(self, other):
+        return list(self) == list(other)
+
+    def columns(self, reference, make):
+        """The per-variant columns of the relation matrix (`relations.matrix.columns_of`): from the library's arrays
+        when they are asked for over the reference the batch was made on, else made from the graphs like any list's."""
+        from ..relations.matrix import columns_of, columns_from_library
+        if self._list is not None:
+            return self._list.columns(reference, make)
+        if make is columns_of and reference == self._reference:
+            if self._columns is None:
+                self._columns = (None, reference, columns_from_library(self))       # (the shape GraphBatch keeps)
+            return self._columns[2]
+        return make(reference, list(self))
 
 
 def trim(lhs, rhs):

@@ -120,6 +120,35 @@ def columns_of(reference, graphs):
     return prep, device_inputs(reference, graphs, prep)
 
 
+class LibraryPrepared:
+    """`Prepared` over a `VariantGraphBatch`: the same columns, as malcs_vgraphs_matrix_columns made them; the list of
+    supremal `Variant`s only when somebody asks (the paths that decide pairs in Python)."""
+
+    def __init__(self, batch, key, symmask, folded):
+        native = batch._native
+        self._batch = batch
+        self.start = np.ascontiguousarray(native.supremal[:, 0])
+        self.end = np.ascontiguousarray(native.supremal[:, 1])
+        self.distance = native.distance
+        self.key, self.symmask, self.folded = key, symmask, folded
+
+    @property
+    def supremal(self):
+        made = self.__dict__.get("_supremal")
+        if made is None:
+            made = self.__dict__["_supremal"] = [g.supremal for g in self._batch]
+        return made
+
+
+def columns_from_library(batch):
+    """`columns_of` for a `VariantGraphBatch` over the reference it was made on."""
+    native = batch._native
+    key, symmask, folded, sup_off, sup, atom_off, atoms = native.matrix_columns(with_atoms=batch._dna)
+    prep = LibraryPrepared(batch, key, symmask, folded)
+    on_device = (batch._ref_codes, sup, sup_off, prep.distance, atoms, atom_off) if (batch._dna and not folded) else None
+    return prep, on_device
+
+
 def compare_matrix(reference, graphs, tile=256, comm=None, rank=0, world=1, gather=None, distance_fn=None, stats=None,
                    tiles_cls=None):
     """uint8 matrix L with L[i, j] = code of compare(reference, graphs[i], graphs[j]).

@@ -240,6 +240,37 @@ int malcs_graphs_canonical(malcs_graphs *graphs, uint64_t i, int64_t *variants4)
  * out[out_range[2 k] .. out_range[2 k + 1]). */
 int malcs_graphs_atoms(malcs_graphs *graphs, uint64_t count, const uint64_t *index, const uint8_t *obs, const uint64_t *obs_off,
                        const uint64_t *out_range, uint8_t *out);
+/* ---- from_variant for many alleles of one reference ------------------------------------------------------
+ * Stands in for LCSgraph.from_variant(reference, variants, offset) (algebra/lcs/lcs_graph.py:77-123) called for n
+ * alleles of ONE reference: allele i replaces ref[start[i] .. end[i]) by ins[ins_off[i] .. ins_off[i + 1]) (the
+ * caller has folded an allele of several variants into that one delins, :95-100).  The widening rounds (:113-123) run
+ * inside the library, every round one device batch over the alleles still widening; an allele that changes nothing is
+ * the graph of two empty sequences (:101-103).  ref / ins: symbol codes below n_symbols.  The handle keeps one
+ * malcs_graphs per round; per allele it gives
+ *   where4     {round, index in that round's handle, lo, hi}: the final window is ref[lo .. hi), shift = lo
+ *   distance, supremal4 {start, end, obs_from, obs_to}      as the graph handle does
+ *   obs_off (n + 1) / observed                               the windows with the alleles in them (codes), back to back:
+ *                                                            allele i's supremal sequence is observed[obs_off[i] + obs_from .. + obs_to)
+ * and, for the relation matrix (algebra/relations/graph_based.py:51-54, 76-79), in one pass:
+ *   key        a number per distinct supremal (start, end, sequence)
+ *   symmask    bit (code mod 64) for every symbol of the supremal sequence; *folded != 0 when a code was 64 or more
+ *   sup        the supremal sequences (codes) at sup_off[i] (n + 1 offsets, the caller's: cumulative obs_to - obs_from)
+ *   atoms      malcs_graphs_atoms of every graph at atom_off[i] (cumulative end - start + 1); DNA codes 0 ... 3 only,
+ *              NULL to leave them out */
+typedef struct malcs_vgraphs malcs_vgraphs;
+int malcs_from_variant_batch(malcs_ctx *ctx, const uint8_t *ref, uint64_t ref_len, uint64_t n, const int64_t *start,
+                             const int64_t *end, const uint8_t *ins, const uint64_t *ins_off, int64_t offset, int n_symbols,
+                             malcs_vgraphs **graphs);
+int malcs_vgraphs_destroy(malcs_vgraphs *graphs);
+uint64_t malcs_vgraphs_size(const malcs_vgraphs *graphs);
+int malcs_vgraphs_columns(const malcs_vgraphs *graphs, int64_t *where4, int64_t *distance, int64_t *supremal4, uint64_t *obs_off);
+int malcs_vgraphs_observed(const malcs_vgraphs *graphs, uint8_t *observed);
+int malcs_vgraphs_rounds(const malcs_vgraphs *graphs, int *n_rounds);
+/* the handle of one round: borrowed -- it lives as long as `graphs` does and is not the caller's to destroy */
+int malcs_vgraphs_round(const malcs_vgraphs *graphs, int round, malcs_graphs **round_graphs, uint64_t *n_pairs);
+int malcs_vgraphs_matrix_columns(malcs_vgraphs *graphs, uint32_t *key, uint64_t *symmask, int *folded, const uint64_t *sup_off,
+                                 uint8_t *sup, const uint64_t *atom_off, uint8_t *atoms);
+
 /* timing split of the last malcs_lcs_graph_batch on this handle, milliseconds:
  * out[0] forward DP kernel, out[1] reach/extract kernel (HIP events), out[2] D2H + host graph build */
 int malcs_graphs_timing(const malcs_graphs *graphs, float *out3);

@@ -123,13 +123,15 @@ def test_compare_matrix_kept_columns():
     same batch re-uses them and gives the same labels, a batch that was changed in between makes them anew, and a
     sub-list (a plain list) never sees them.  The matrix itself sits in pinned host memory and is an ordinary array."""
     from algebra_amd.lcs import LCSgraph
-    from algebra_amd.lcs.lcs_graph import GraphBatch
+    from collections.abc import MutableSequence
+    from algebra_amd.lcs.lcs_graph import VariantGraphBatch
     from algebra_amd.relations import compare_matrix
     from algebra_amd.variants import Variant
     case = SEQS["matrices"][0]
     want = np.array(case["labels"], dtype=np.uint8)
     graphs = LCSgraph.from_variant_batch(case["reference"], [[Variant(*v)] for v in case["variants"]])
-    assert isinstance(graphs, GraphBatch) and isinstance(graphs, list)
+    assert isinstance(graphs, VariantGraphBatch) and isinstance(graphs, MutableSequence)   # the library ran the widening rounds
+    assert not any(graphs._made)                                 # ... and no graph object exists yet
     first = compare_matrix(case["reference"], graphs, tile=16)
     columns = graphs._columns[2]
     second = compare_matrix(case["reference"], graphs, tile=16)
@@ -138,10 +140,11 @@ def test_compare_matrix_kept_columns():
     first[0, 0] = 7                                              # writable, and not shared with the next result
     assert compare_matrix(case["reference"], graphs, tile=16)[0, 0] == 0
     # the batch changes: two graphs swapped, then one dropped
+    assert not any(graphs._made)                                 # three matrices later: still arrays only
     graphs[0], graphs[5] = graphs[5], graphs[0]
     order = [5] + list(range(1, 5)) + [0] + list(range(6, len(graphs)))
     assert np.array_equal(compare_matrix(case["reference"], graphs, tile=16), want[np.ix_(order, order)])
-    assert graphs._columns[2] is not columns
+    assert graphs._list._columns[2] is not columns
     del graphs[3]
     order.pop(3)
     assert np.array_equal(compare_matrix(case["reference"], graphs, tile=16), want[np.ix_(order, order)])
@@ -170,6 +173,55 @@ def test_from_variant_batch_equals_singles():
     for rec in REF["from_variant"]:
         got = LCSgraph.from_variant_batch(rec["reference"], [[Variant(*v) for v in rec["variants"]]], rec["offset"])[0]
         assert graph_record(got) == rec["graph"]
+
+
+def test_from_variant_batch_other_alphabets_and_fallback():
+    """The library's widening rounds (malcs_from_variant_batch) over symbols that are not A, C, G, T -- its own code
+    table, columns without atom masks -- and the facade's own rounds where the library's entry does not apply (a symbol
+    beyond Latin-1): the same graphs as from_variant one by one, the same matrix as compare() pair by pair."""
+    from algebra_amd.lcs import LCSgraph
+    from algebra_amd.lcs.lcs_graph import GraphBatch, VariantGraphBatch
+    from algebra_amd.relations import compare_matrix
+    from algebra_amd.relations.graph_based import compare
+    from algebra_amd.relations.relation import CODES
+    from algebra_amd.variants import Variant
+    from util import graph_record
+    rs = np.random.RandomState(77)
+    for alphabet, kind in (("ACDEFGHIKLMNPQRSTVWY", VariantGraphBatch), ("AC\u0416T", GraphBatch)):
+        reference = "".join(alphabet[k] for k in rs.randint(0, len(alphabet), 300))
+        alleles = []
+        for _ in range(40):
+            start = int(rs.randint(0, 290))
+            end = start + int(rs.randint(0, 6))
+            ins = "".join(alphabet[k] for k in rs.randint(0, len(alphabet), rs.randint(0, 5)))
+            alleles.append([Variant(start, end, ins)])
+        alleles += [[], [Variant(10, 12, reference[10:12])], [Variant(0, 0, alphabet[1]), Variant(299, 300, "")]]
+        batch = LCSgraph.from_variant_batch(reference, alleles, offset=3)
+        assert type(batch) is kind and len(batch) == len(alleles)
+        singles = [LCSgraph.from_variant(reference, allele, offset=3) for allele in alleles]
+        for got, want in zip(batch, singles):
+            assert graph_record(got) == graph_record(want)
+        labels = compare_matrix(reference, batch, tile=16)
+        for i in range(0, len(alleles), 5):
+            for j in range(len(alleles)):
+                assert labels[i, j] == CODES[compare(reference, singles[i], singles[j])], (i, j)
+
+
+def test_from_variant_batch_bad_arguments():
+    from algebra_amd import _native
+    ctx = _native.default_context()
+    ref = np.zeros(20, np.uint8)
+    with pytest.raises(_native.MalcsError, match="not an interval of the reference"):
+        _native.VariantGraphs(ctx, ref, [5], [30], np.zeros(1, np.uint8), [0, 0], 10, 4)
+    with pytest.raises(_native.MalcsError, match="not an interval of the reference"):
+        _native.VariantGraphs(ctx, ref, [7], [5], np.zeros(1, np.uint8), [0, 0], 10, 4)
+    with pytest.raises(_native.MalcsError, match="n_symbols"):
+        _native.VariantGraphs(ctx, ref, [5], [6], np.zeros(1, np.uint8), [0, 1], 10, 0)
+    none = _native.VariantGraphs(ctx, ref, [], [], np.zeros(1, np.uint8), [0], 10, 4)
+    assert none.n == 0 and none.n_rounds == 0
+    key, symmask, folded, sup_off, sup, atom_off, atoms = none.matrix_columns(with_atoms=True)
+    assert len(key) == 0 and sup_off.tolist() == [0] and not folded
+    none.close()
 
 
 def test_extract_sequence_batch_equals_singles():
