@@ -49,6 +49,7 @@ namespace {
 using namespace malcs_dev;
 
 constexpr int META_ROWS = 4;          // pid, m, n, kmax | retry class << 16
+constexpr uint32_t JOIN_WORDS = 3;        // 64-bit words per lane a cut tile has in the join buffer: the word the parts swap, the front part's rows, the back part's
 constexpr int MALCS_DIAG_HALF_T = 48; // two limbs moving 16 rows per 16 columns: 64 - 16 diagonals
 
 #include "malcs_plan.inc"
@@ -511,7 +512,7 @@ k_llcs_diag(const uint32_t *__restrict__ rows, const uint32_t *__restrict__ piec
     }
     if (!info) return;                                 // the grid is an upper bound of the plan's pieces (decided on the device)
     // the tile's slots in the join buffer (one 64-bit word per lane); for a piece that is not joined: the first tile's, unused
-    const unsigned long long *const join_slots = reinterpret_cast<const unsigned long long *>(join_buf) + (size_t)((info & PIECE_JOINED) ? jt : 0u) * 64u;
+    const unsigned long long *const join_slots = reinterpret_cast<const unsigned long long *>(join_buf) + (size_t)((info & PIECE_JOINED) ? jt : 0u) * (JOIN_WORDS * 64u);
     const uint32_t *rows_u = rows + (size_t)off_s * 64u;                                               // the piece's rows
     const uint32_t *p = rows_u + lane;
     const int iters = (int)(info & PIECE_BLOCKS);
@@ -545,7 +546,7 @@ k_llcs_diag(const uint32_t *__restrict__ rows, const uint32_t *__restrict__ piec
     // order, so no barrier
     __shared__ uint32_t join_tab[NLW == 3 && NP == 2 && FUSED ? 256 : 1];
     if constexpr (NLW == 3 && NP == 2 && FUSED) {
-        if (halves && (info & PIECE_JOINED)) {
+        if (info & PIECE_JOINED) {
 #pragma unroll
             for (int j = 0; j < 4; j++) {
                 const uint32_t idx = lane * 4u + (uint32_t)j;
@@ -693,10 +694,64 @@ k_llcs_diag(const uint32_t *__restrict__ rows, const uint32_t *__restrict__ piec
             }
             it++;
         }
-        uint32_t zeros = banked - (uint32_t)above;
+        bool joined3 = false;
+        if constexpr (NLW == 3 && NP == 2 && FUSED) {
+            if (info & PIECE_JOINED) {
+                // A part of a cut tile in three-limb mode.  As in two-limb mode (above) the window now holds rows
+                // [32 iters - kmax, + 96), all inside the matrix, and the join needs the first S = 2 kmax - delta (63 or
+                // 64) of them and the zeros that left: 64 + 17 bits, two words.  The rows go to the part's own word of
+                // the tile's slot first and are WAITED for (an agent-scope store is at the memory side when it is
+                // acknowledged), then the count is swapped in as in two-limb mode: whoever gets the other part's count
+                // back finds its rows there, whatever the order in which the two parts' words travelled.
+                joined3 = true;
+                skip = true;
+                const bool back = info & PIECE_BACK;
+                if (pid != 0xffffffffu) {
+                    unsigned long long *slot = const_cast<unsigned long long *>(join_slots) + lane;
+                    const uint64_t mv = ((uint64_t)V[1] << 32) | V[0];
+                    __hip_atomic_store(slot + (back ? 128 : 64), mv, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                    const uint32_t left = banked - (uint32_t)above;          // zero bits of the rows that left, inside the matrix
+                    const uint64_t theirs = __hip_atomic_exchange(slot, (uint64_t)left + 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    if (theirs != 0ull) {
+                        const uint64_t ov = __hip_atomic_load(slot + (back ? 64 : 128), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        __hip_atomic_store(slot, 0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        const uint32_t oleft = (uint32_t)theirs - 1u;
+                        const uint64_t Vf = back ? ov : mv, Vb = back ? mv : ov;
+                        const int S = 2 * kmax - (int)(n - m);                       // 63 or 64
+                        const uint64_t ms = S >= 64 ? ~0ull : ((1ull << S) - 1ull);
+                        const uint64_t Am = ~Vf & ms, B = ~Vb & ms;
+                        const uint64_t Br = __brevll(B) >> (64 - S);                 // bit x: row S - 1 - x of the back window
+                        const uint32_t a0 = (uint32_t)Am, a1 = (uint32_t)(Am >> 32), b0 = (uint32_t)Br, b1 = (uint32_t)(Br >> 32);
+                        const uint32_t x0 = (a0 & 0x0f0f0f0fu) | ((b0 << 4) & 0xf0f0f0f0u), y0 = ((a0 >> 4) & 0x0f0f0f0fu) | (b0 & 0xf0f0f0f0u);
+                        const uint32_t x1 = (a1 & 0x0f0f0f0fu) | ((b1 << 4) & 0xf0f0f0f0u), y1 = ((a1 >> 4) & 0x0f0f0f0fu) | (b1 & 0xf0f0f0f0u);
+                        int t = 0, best = 0;
 #pragma unroll
-        for (int k = 0; k < NLW - 1; k++) zeros += __popc(~V[k] & rowmask(32 * (iters + k) - kmax));
-        d = (int32_t)(m + n - 2u * zeros);
+                        for (int k = 0; k < 4; k++) {
+                            const uint32_t e0 = join_tab[(x0 >> (8 * k)) & 0xffu], e1 = join_tab[(y0 >> (8 * k)) & 0xffu];
+                            best = max(best, t + (int)(e0 & 0xffffu)); t += (int)e0 >> 16;
+                            best = max(best, t + (int)(e1 & 0xffffu)); t += (int)e1 >> 16;
+                        }
+#pragma unroll
+                        for (int k = 0; k < 4; k++) {
+                            const uint32_t e0 = join_tab[(x1 >> (8 * k)) & 0xffu], e1 = join_tab[(y1 >> (8 * k)) & 0xffu];
+                            best = max(best, t + (int)(e0 & 0xffffu)); t += (int)e0 >> 16;
+                            best = max(best, t + (int)(e1 & 0xffffu)); t += (int)e1 >> 16;
+                        }
+                        best += __popcll(B);
+                        const uint32_t zeros = left + oleft + (uint32_t)best;
+                        d = (int32_t)(m + n - 2u * zeros);
+                        skip = false;
+                    }
+                }
+            }
+        }
+        if (!joined3) {
+            uint32_t zeros = banked - (uint32_t)above;
+#pragma unroll
+            for (int k = 0; k < NLW - 1; k++) zeros += __popc(~V[k] & rowmask(32 * (iters + k) - kmax));
+            d = (int32_t)(m + n - 2u * zeros);
+        }
     }
 
     stamp(3);
@@ -858,7 +913,7 @@ int malcs_diag_setup(malcs_batch *b, int nlw, const std::vector<uint32_t> &pairs
     const size_t at_tab = carve(keep, (size_t)7 * n_launch + 4);
     const size_t at_list = carve(keep, std::max<uint32_t>(acc, 1)), at_first = carve(keep, ncls), at_cap = carve(keep, ncls);
     const size_t at_count = carve(keep, 2 * ncls);                         // two sets, used by alternate launches
-    const size_t at_jbuf = carve(keep, (size_t)(cut_possible ? n_tiles : 1u) * 128u);   // one 64-bit word per lane of a cut tile
+    const size_t at_jbuf = carve(keep, (size_t)(cut_possible ? n_tiles : 1u) * JOIN_WORDS * 128u);   // JOIN_WORDS 64-bit words per lane of a cut tile
     const size_t at_stats = carve(keep, PS_FIELDS);
     const size_t at_sample = carve(keep, (size_t)(5 * SAMPLE_SLOTS + 1) * n_sample + 64), at_sdist = carve(keep, (size_t)SAMPLE_SLOTS * n_sample + 64);
     MALCS_HIP(malcs_pool_alloc(ctx, (void **)&d.d_rows, keep * sizeof(uint32_t)));

@@ -200,7 +200,8 @@ def check_window_plan(batch):
         assert got, t
         assert sum(g[0] for g in got) == longest, ("blocks of tile", t, got, longest)
         if len(got) == 2:
-            assert got[0][1] & 0xC == 0xC and got[1][1] & 0xE == 0xE, "flags of a cut tile"     # half | joined (| back)
+            assert got[0][1] & 0x6 == 0x4 and got[1][1] & 0x6 == 0x6, "flags of a cut tile"     # joined (| back)
+            assert (got[0][1] ^ got[1][1]) & 0x9 == 0, "both parts of a tile run in the same mode"
             assert min(g[0] for g in got) >= 2
         for blocks, _, off in got:
             spans.append((off, off + rows_fixed + blocks * 4))
