@@ -51,6 +51,7 @@ def _load():
         "malcs_edit_distance_time": (c.c_int, [vp, c.c_int, P(c.c_float)]),
         "malcs_edit_distance_time_kernel": (c.c_int, [vp, c.c_int, P(c.c_float)]),
         "malcs_edit_distance_kernel_durations": (c.c_int, [vp, c.c_int, vp]),
+        "malcs_edit_distance_step_durations": (c.c_int, [vp, c.c_int, vp]),
         "malcs_batch_plan_info": (c.c_int, [vp, P(c.c_uint64)]),
         "malcs_batch_plan_dump": (c.c_int, [vp, c.c_int, vp, c.c_uint64, P(c.c_uint64)]),
         "malcs_edit_distance_batch": (c.c_int, [vp, vp, u64, vp, vp, vp, vp, u64, c.c_int, vp]),
@@ -296,6 +297,12 @@ class Batch:
         """ms of each of `iters` back-to-back launches of the window kernel (one HIP event pair per launch)."""
         out = np.zeros(int(iters), dtype=np.float32)
         check(lib.malcs_edit_distance_kernel_durations(self.handle, int(iters), ptr(out)))
+        return out
+
+    def step_durations(self, iters):
+        """ms of the window kernel in each of `iters` whole steps (replan + launch) queued back to back."""
+        out = np.zeros(int(iters), dtype=np.float32)
+        check(lib.malcs_edit_distance_step_durations(self.handle, int(iters), ptr(out)))
         return out
 
     def plan_info(self):

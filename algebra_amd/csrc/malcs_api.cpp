@@ -772,6 +772,27 @@ int malcs_edit_distance_kernel_durations(malcs_batch *b, int iters, float *ms_ea
     return rc;
 }
 
+int malcs_edit_distance_step_durations(malcs_batch *b, int iters, float *ms_each)
+{
+    if (!b || !ms_each || iters < 1) { malcs_set_error("bad argument"); return MALCS_ERR_ARG; }
+    if (!b->diag.nlw) { malcs_set_error("the batch has no window class"); return MALCS_ERR_ARG; }
+    malcs_ctx *c = b->ctx;
+    MALCS_HIP(hipSetDevice(c->device));
+    std::vector<hipEvent_t> ev((size_t)2 * iters, nullptr);
+    int rc = MALCS_OK;
+    for (hipEvent_t &e : ev)
+        if (hipEventCreate(&e) != hipSuccess) { (void)hipGetLastError(); malcs_set_error("hipEventCreate failed"); rc = MALCS_ERR_HIP; break; }
+    for (int i = 0; i < iters && rc == MALCS_OK; i++) {
+        rc = malcs_dist_replan(b);
+        if (rc == MALCS_OK) rc = malcs_dist_launch(b, ev[2 * (size_t)i], ev[2 * (size_t)i + 1]);
+    }
+    if (hipStreamSynchronize(c->stream) != hipSuccess && rc == MALCS_OK) { malcs_set_error("synchronisation failed"); rc = MALCS_ERR_HIP; }
+    for (int i = 0; i < iters && rc == MALCS_OK; i++)
+        if (hipEventElapsedTime(&ms_each[i], ev[2 * (size_t)i], ev[2 * (size_t)i + 1]) != hipSuccess) { (void)hipGetLastError(); malcs_set_error("hipEventElapsedTime failed"); rc = MALCS_ERR_HIP; }
+    for (hipEvent_t e : ev) if (e) (void)hipEventDestroy(e);
+    return rc;
+}
+
 int malcs_batch_plan_info(malcs_batch *b, uint64_t *info)
 {
     if (!b || !info) { malcs_set_error("NULL argument"); return MALCS_ERR_ARG; }

@@ -438,20 +438,20 @@ int malcs_dist_plan(malcs_batch *b)
 // queued on the context's stream -- nothing comes back to the host.
 int malcs_dist_replan(malcs_batch *b) { return malcs_diag_plan(b); }
 
-int malcs_dist_launch(malcs_batch *b)
+int malcs_dist_launch(malcs_batch *b, hipEvent_t window_start, hipEvent_t window_stop)
 {
-    int rc = malcs_dist_launch_resident(b);
+    int rc = malcs_dist_launch_resident(b, window_start, window_stop);
     if (rc) return rc;
     if (!b->band_pairs.empty()) return malcs_dist_band(b, b->band_pairs, nullptr);
     return MALCS_OK;
 }
 
 // everything but the pairs beyond a resident pattern (b->band_pairs)
-int malcs_dist_launch_resident(malcs_batch *b)
+int malcs_dist_launch_resident(malcs_batch *b, hipEvent_t window_start, hipEvent_t window_stop)
 {
     // window class first, then the full-matrix kernel over whatever it left undecided
     if (b->diag.nlw) {
-        int rc = malcs_diag_launch(b, true);
+        int rc = malcs_diag_launch(b, true, window_start, window_stop);
         if (rc) return rc;
         for (size_t c = 0; c < b->diag.retry.size(); c++) {
             const diag_retry &r = b->diag.retry[c];

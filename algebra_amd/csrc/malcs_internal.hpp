@@ -248,8 +248,8 @@ int malcs_diag_threshold(int nlw);
 // malcs_dist.hip
 int malcs_dist_plan(malcs_batch *b);          // classes from the lengths (host) + malcs_dist_replan
 int malcs_dist_replan(malcs_batch *b);        // what depends on the sequences: the window class's plan, on the device
-int malcs_dist_launch(malcs_batch *b);
-int malcs_dist_launch_resident(malcs_batch *b);
+int malcs_dist_launch(malcs_batch *b, hipEvent_t window_start = nullptr, hipEvent_t window_stop = nullptr);   // events: around the window kernel of the step
+int malcs_dist_launch_resident(malcs_batch *b, hipEvent_t window_start = nullptr, hipEvent_t window_stop = nullptr);
 int malcs_dist_band(malcs_batch *b, const std::vector<uint32_t> &pairs, int32_t *host_out);
 int malcs_dist_launch_list(hipStream_t st, int n_planes, int W, int L, const uint32_t *d_planes,
                            const uint32_t *d_a_off, const uint32_t *d_a_len, const uint32_t *d_b_off, const uint32_t *d_b_len,

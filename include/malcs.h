@@ -142,6 +142,10 @@ int malcs_edit_distance_time_kernel(malcs_batch *batch, int iters, float *ms_tot
  * duration; the gap between two kernels of a stream is in _time_kernel's total and not in these).  ms_each[iters].
  * Measurement only, like the two above: no counterpart in the reference.  Error when the batch has no window class. */
 int malcs_edit_distance_kernel_durations(malcs_batch *batch, int iters, float *ms_each);
+/* As _kernel_durations, but every launch is the window kernel of a whole step (malcs_batch_replan +
+ * malcs_edit_distance_launch, `iters` steps queued back to back): the kernel as it runs behind the plan that has just
+ * written its rows, which is a few microseconds slower than a replay.  Measurement only; no counterpart in the reference. */
+int malcs_edit_distance_step_durations(malcs_batch *batch, int iters, float *ms_each);
 
 /* One-shot convenience: create + launch + fetch + destroy. */
 int malcs_edit_distance_batch(malcs_ctx *ctx, const uint8_t *syms, uint64_t n_syms,
