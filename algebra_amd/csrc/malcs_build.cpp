@@ -131,6 +131,9 @@ struct pair_graph {
     // needs the int64 arrays in place (widen()), the copy-out entry points widen on the way
     bool narrow = false;
     const int32_t *dev_nodes = nullptr, *dev_edges = nullptr;
+    const int16_t *dev_nodes16 = nullptr, *dev_edges16 = nullptr;      // ... or as int16 (graphs the device built over windows below 32 768)
+    int64_t node_word(size_t i) const { return dev_nodes16 ? dev_nodes16[i] : dev_nodes[i]; }
+    int64_t edge_word(size_t i) const { return dev_edges16 ? dev_edges16[i] : dev_edges[i]; }
     const uint32_t *dev_runs = nullptr;      // its runs as the kernels left them (sorted, without the shift), 4 per run
     int64_t dev_n_nodes = 0, dev_n_edges = 0, dev_n_runs = 0, dev_shift = 0;
     bool dev_built = false;
@@ -522,13 +525,13 @@ static void widen(malcs_graphs *g, pair_graph &G)
     G.nodes = g->stores[0].take((size_t)G.dev_n_nodes * 3);
     G.edges = g->stores[0].take((size_t)G.dev_n_edges * 6);
     for (int64_t v = 0; v < G.dev_n_nodes; v++) {
-        G.nodes[3 * v] = G.dev_nodes[3 * v] + G.dev_shift; G.nodes[3 * v + 1] = G.dev_nodes[3 * v + 1] + G.dev_shift;
-        G.nodes[3 * v + 2] = G.dev_nodes[3 * v + 2];
+        G.nodes[3 * v] = G.node_word(3 * v) + G.dev_shift; G.nodes[3 * v + 1] = G.node_word(3 * v + 1) + G.dev_shift;
+        G.nodes[3 * v + 2] = G.node_word(3 * v + 2);
     }
     for (int64_t e = 0; e < G.dev_n_edges; e++) {
-        const int32_t *x = G.dev_edges + 6 * e;
         int64_t *o = &G.edges[6 * e];
-        o[0] = x[0]; o[1] = x[1]; o[2] = x[2] + G.dev_shift; o[3] = x[3] + G.dev_shift; o[4] = x[4]; o[5] = x[5];
+        o[0] = G.edge_word(6 * e); o[1] = G.edge_word(6 * e + 1); o[2] = G.edge_word(6 * e + 2) + G.dev_shift;
+        o[3] = G.edge_word(6 * e + 3) + G.dev_shift; o[4] = G.edge_word(6 * e + 4); o[5] = G.edge_word(6 * e + 5);
     }
 }
 
@@ -643,11 +646,14 @@ static int gbuild_hook(void *user_, const malcs_sweep_chunk &c)
             if (po[0] != 0) continue;                                     // given up: the host half builds this one
             const uint64_t at = (uint64_t)(uint32_t)po[7] | ((uint64_t)(uint32_t)po[8] << 32);
             const uint64_t n_nodes = (uint64_t)po[1], n_edges = (uint64_t)po[2];
-            if (at < reach[k] || at + 3 * n_nodes + 6 * n_edges > reach[k + 1]) continue;
+            const bool half16 = (po[9] >> 30) & 1;                            // node / edge words as int16
+            const uint64_t items = 3 * n_nodes + 6 * n_edges;
+            if (at < reach[k] || at + (half16 ? (items + 1) / 2 : items) > reach[k + 1]) continue;
             pair_graph &G = u.out->g[c.pids[f]];
             const int64_t sh = u.shift ? u.shift[c.pids[f]] : 0;
             const int32_t *words = home[k] + (at - reach[k]);
-            G.dev_nodes = words; G.dev_edges = words + 3 * n_nodes;
+            if (half16) { G.dev_nodes16 = reinterpret_cast<const int16_t *>(words); G.dev_edges16 = G.dev_nodes16 + 3 * n_nodes; }
+            else { G.dev_nodes = words; G.dev_edges = words + 3 * n_nodes; }
             G.dev_n_nodes = (int64_t)n_nodes; G.dev_n_edges = (int64_t)n_edges; G.dev_shift = sh;
             G.supremal[0] = po[3] + sh; G.supremal[1] = po[4] + sh; G.supremal[2] = po[5]; G.supremal[3] = po[6];
             G.dev_built = true;
@@ -1224,7 +1230,7 @@ int malcs_graphs_nodes(const malcs_graphs *g, uint64_t i, int64_t *dst)
         const pair_graph &G = g->g[i];
         if (!dst && G.dev_n_nodes) { malcs_set_error("bad argument"); return MALCS_ERR_ARG; }
         for (int64_t v = 0; v < G.dev_n_nodes; v++) {
-            dst[3 * v] = G.dev_nodes[3 * v] + G.dev_shift; dst[3 * v + 1] = G.dev_nodes[3 * v + 1] + G.dev_shift; dst[3 * v + 2] = G.dev_nodes[3 * v + 2];
+            dst[3 * v] = G.node_word(3 * v) + G.dev_shift; dst[3 * v + 1] = G.node_word(3 * v + 1) + G.dev_shift; dst[3 * v + 2] = G.node_word(3 * v + 2);
         }
         return MALCS_OK;
     }
@@ -1236,9 +1242,9 @@ int malcs_graphs_edges(const malcs_graphs *g, uint64_t i, int64_t *dst)
         const pair_graph &G = g->g[i];
         if (!dst && G.dev_n_edges) { malcs_set_error("bad argument"); return MALCS_ERR_ARG; }
         for (int64_t e = 0; e < G.dev_n_edges; e++) {
-            const int32_t *x = G.dev_edges + 6 * e;
             int64_t *o = dst + 6 * e;
-            o[0] = x[0]; o[1] = x[1]; o[2] = x[2] + G.dev_shift; o[3] = x[3] + G.dev_shift; o[4] = x[4]; o[5] = x[5];
+            o[0] = G.edge_word(6 * e); o[1] = G.edge_word(6 * e + 1); o[2] = G.edge_word(6 * e + 2) + G.dev_shift;
+            o[3] = G.edge_word(6 * e + 3) + G.dev_shift; o[4] = G.edge_word(6 * e + 4); o[5] = G.edge_word(6 * e + 5);
         }
         return MALCS_OK;
     }

@@ -86,21 +86,29 @@ k_graph_build(uint4 *__restrict__ runs, const uint64_t *__restrict__ run_off, co
         const int32_t n_levels = (m + n - dist[pid]) / 2;
         int32_t source = 0, sink = 0, sup[4] = {0, 0, 0, 0};
         malcs_core::build(A, m, n, shift ? shift[pid] : 0, sorted, (int32_t)R, n_levels, source, sink, sup, malcs_core::no_growth());
-        int32_t status = A.overflow ? 1 : 0, count = 0;
+        int32_t status = A.overflow ? 1 : 0, count = 0, R16 = 0;
         int64_t n_edges = 0;
         unsigned long long at = 0;
         if (!status) {
             count = malcs_core::count_reachable(A, source, n_edges);
-            const unsigned long long words = 3ull * (unsigned)count + 6ull * (unsigned long long)n_edges;
+            // windows below 32 768 symbols: node triples and edge tuples as int16 (half the words to bring home -- 104 MB for
+            // 100 000 C2 graphs otherwise); the cursor counts int32 words either way
+            const bool half16 = m < 32768 && n < 32768 && count < 32768;
+            const unsigned long long items = 3ull * (unsigned)count + 6ull * (unsigned long long)n_edges;
+            const unsigned long long words = half16 ? (items + 1ull) / 2ull : items;
             if (n_edges > 0x7fffffffll) status = 1;
             else {
                 at = atomicAdd(out_cursor, words);
                 if (at + words > out_cap) status = 1;                      // the output buffer is full: the host half takes the pair
-                else malcs_core::write_graph<int32_t>(A, source, out_words + at, out_words + at + 3ull * (unsigned)count, 0);
+                else if (half16) {
+                    int16_t *o = reinterpret_cast<int16_t *>(out_words + at);
+                    malcs_core::write_graph<int16_t>(A, source, o, o + 3ull * (unsigned)count, 0);
+                } else malcs_core::write_graph<int32_t>(A, source, out_words + at, out_words + at + 3ull * (unsigned)count, 0);
+                if (half16) R16 = 1 << 30;
             }
         }
         po[0] = status; po[1] = count; po[2] = (int32_t)n_edges; po[3] = sup[0]; po[4] = sup[1]; po[5] = sup[2]; po[6] = sup[3];
-        po[7] = (int32_t)(uint32_t)at; po[8] = (int32_t)(uint32_t)(at >> 32); po[9] = (int32_t)R;
+        po[7] = (int32_t)(uint32_t)at; po[8] = (int32_t)(uint32_t)(at >> 32); po[9] = (int32_t)R | R16;        // bit 30: int16 words
     }
     (void)bcast;
 }
