@@ -732,6 +732,7 @@ static int graph_batch(malcs_batch *b, const int64_t *shift, const int64_t *max_
     const int band_wmax = malcs_graph_max_band_words(b->n_planes);
     auto band_capacity = [](int W) { const int G = 64 * W; return 61 * (G + 1) - G - 64; };
     std::vector<launch_class> classes;
+    const bool resident_band = !(getenv("MALCS_GRAPH_RESIDENT_BAND") && atoi(getenv("MALCS_GRAPH_RESIDENT_BAND")) == 0);   // 0: resident windows store every group's tie bits
     int64_t small_rows = 192;                           // shorter windows stay with the bit-vector kernels (64 pairs per wave)
     if (const char *e = getenv("MALCS_SWEEP_MIN_ROWS")) small_rows = atoll(e);
     int64_t small_ratio = 8;                            // ... as do windows further apart than length / 8
@@ -759,7 +760,13 @@ static int graph_batch(malcs_batch *b, const int64_t *shift, const int64_t *max_
         }
         if (m < 4096u) {
             const uint32_t words = m / 64u + 1u;
-            if (words <= 4) W = (int)pow2ceil(words);
+            if (resident_band && words >= 4 && 4 * (G.distance + 2) <= (int64_t)m) {
+                // all groups resident, but only the band's tie bits stored (the distance is known: the band kernels' bounds):
+                // groups of 64 rows, so that the two or three groups a column's band touches are a fraction of the window
+                W = 1;
+                const uint32_t lanes = pow2ceil(words);
+                while ((1u << logL) < lanes) logL++;
+            } else if (words <= 4) W = (int)pow2ceil(words);
             else { W = 4; const uint32_t lanes = pow2ceil((words + 3u) / 4u); while ((1u << logL) < lanes) logL++; }
         } else {
             band = true;
@@ -828,11 +835,12 @@ static int graph_batch(malcs_batch *b, const int64_t *shift, const int64_t *max_
                 const uint32_t pid = lc.pairs[pos];
                 const int64_t m = b->a_len[pid], n = b->b_len[pid], D = dist[pid];
                 int32_t lo = -(1 << 30), hi = 1 << 30, groups = 1 << lc.logL;
-                if (lc.band) {
+                if (lc.band || resident_band) {
                     const int64_t delta = n - m;
                     lo = (int32_t)(-((D - delta) / 2) - 1);
                     hi = (int32_t)((D + delta) / 2 + 1);
-                    groups = (int32_t)(((int64_t)hi - lo) >> logG) + 2;
+                    const int32_t in_band = (int32_t)(((int64_t)hi - lo) >> logG) + 2;
+                    groups = lc.band ? in_band : std::min(groups, in_band);        // (resident: never more than the window has)
                 }
                 // columns 0 ... n, one record per group in the band; resident windows index by systolic step (column + group)
                 const uint64_t need = ((uint64_t)n + 1ull + (lc.band ? 0ull : (uint64_t)groups)) * (uint64_t)groups * 2ull * NL;

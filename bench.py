@@ -134,27 +134,38 @@ def extra_configs(ctx, _native, gen):
                             "host_build_ms": round(float(g.timing[2]), 1)}
     g.close()
     batch.close()
-    # the same shape through the bit-vector kernels (what divergent windows use): HBM-bound tie-bit rows
-    n = 100000                                                 # 25 GB of tie bits each way (3.0 / 3.8 TB/s; 20 000 pairs: 2.7 / 2.9)
-    os.environ["MALCS_SWEEP_DMAX"] = "-1"
-    batch = _native.Batch(ctx, *gen.c2_batch(n, seed=12), 4)
-    batch.graphs().close()
-    t0 = time.perf_counter()
-    g = batch.graphs()
-    wall = time.perf_counter() - t0
-    del os.environ["MALCS_SWEEP_DMAX"]
-    out["c2_lcs_graphs_bitvector"] = {"pairs": n, "graphs_per_s": round(n / wall, 1), "forward_ms": round(float(g.timing[0]), 3),
-                                      "reach_ms": round(float(g.timing[1]), 3), "host_build_ms": round(float(g.timing[2]), 1),
-                                      "tie_bit_GB_per_s": {"forward_write": round(n * 1e6 * 0.25 / (float(g.timing[0]) * 1e-3) / 1e9, 1),
-                                                           "reach_read": round(n * 1e6 * 0.25 / (float(g.timing[1]) * 1e-3) / 1e9, 1)}}
-    # family 2's own roofline (HBM): 0.25 B of tie bits per cell written by the forward pass, read by the
-    # backward pass; 1e6 cells per pair; stage times by HIP events on the library's stream (all launches of the stage)
-    for stage, key, kernel in (("forward", "forward_ms", "k_lcs_forward<W,2,BAND>"), ("reach", "reach_ms", "k_lcs_reach<W,2,BAND>")):
-        gbs = n * 1e6 * 0.25 / (out["c2_lcs_graphs_bitvector"][key] * 1e-3) / 1e9
-        out["c2_lcs_graphs_bitvector"]["roofline_" + stage] = {"bound": "hbm", "kernel": kernel, "achieved": round(gbs, 1), "peak": 8000.0,
-                                                                "unit": "GB/s", "frac": round(gbs / 8000.0, 4)}
-    g.close()
-    batch.close()
+    # the same shape through the bit-vector kernels (what short or divergent windows use).  Since round 3 windows that
+    # are close to their reference store the tie bits of the band only (groups of 64 rows; the distance is known from
+    # family 1): 25.7 -> 3.2 GB per 100 000 pairs, and the two kernels are no longer bound by HBM.  The second run stores
+    # every group (MALCS_GRAPH_RESIDENT_BAND=0): that one IS the HBM-bound case, with family 2's own roofline
+    # (0.25 B of tie bits per cell written by the forward pass, read by the backward pass; profiles/r03_family2_*).
+    n = 100000
+    cells = float(n) * 1e6
+    for key, env in (("c2_lcs_graphs_bitvector", None), ("c2_lcs_graphs_bitvector_all_groups", "0")):
+        os.environ["MALCS_SWEEP_DMAX"] = "-1"
+        if env is not None:
+            os.environ["MALCS_GRAPH_RESIDENT_BAND"] = env
+        try:
+            batch = _native.Batch(ctx, *gen.c2_batch(n, seed=12), 4)
+            batch.graphs().close()
+            t0 = time.perf_counter()
+            g = batch.graphs()
+            wall = time.perf_counter() - t0
+        finally:
+            del os.environ["MALCS_SWEEP_DMAX"]
+            os.environ.pop("MALCS_GRAPH_RESIDENT_BAND", None)
+        fwd, rch, tie = float(g.timing[0]), float(g.timing[1]), float(g.tie_bytes)
+        rec = {"pairs": n, "graphs_per_s": round(n / wall, 1), "forward_ms": round(fwd, 3), "reach_ms": round(rch, 3),
+               "host_build_ms": round(float(g.timing[2]), 1), "tie_bytes": int(tie),
+               "cells_per_s": {"forward": round(cells / (fwd * 1e-3), 1), "reach": round(cells / (rch * 1e-3), 1)},
+               "tie_bit_GB_per_s": {"forward_write": round(tie / (fwd * 1e-3) / 1e9, 1), "reach_read": round(tie / (rch * 1e-3) / 1e9, 1)}}
+        for stage, ms, kernel in (("forward", fwd, "k_lcs_forward<W,2,false>"), ("reach", rch, "k_lcs_reach<W,2,false>")):
+            gbs = tie / (ms * 1e-3) / 1e9
+            rec["roofline_" + stage] = {"bound": "hbm" if env == "0" else "valu (the band's tie bits no longer fill the link; the HBM figure is kept beside it)",
+                                        "kernel": kernel, "achieved": round(gbs, 1), "peak": 8000.0, "unit": "GB/s", "frac": round(gbs / 8000.0, 4)}
+        out[key] = rec
+        g.close()
+        batch.close()
     return out
 
 
