@@ -46,6 +46,8 @@ int malcs_gbuild_launch(malcs_ctx *ctx, int kind, uint4 *d_runs, const uint64_t 
                         const uint64_t *d_scratch_off, int32_t *d_out_words, uint64_t out_cap, unsigned long long *d_out_cursor,
                         int32_t *d_pair_out);
 int malcs_sweep_small_dmax();
+int malcs_gbuild_events_to_runs(malcs_ctx *ctx, int kind, const void *d_events, const uint64_t *d_ev_off, const uint32_t *d_ev_cnt,
+                                const uint32_t *d_slots, uint32_t n_slots, uint4 *d_runs, const uint64_t *d_run_off, uint32_t *d_run_cnt);
 
 namespace {
 
@@ -505,6 +507,7 @@ struct malcs_graphs {
     std::deque<i64_store> stores;   // one per worker thread
     std::deque<i32_store> narrow;   // likewise: the int32 arrays of the graphs built on the host
     std::deque<pinned_vec<int32_t>> dev_words;    // graphs the device built, one buffer per chunk of pairs
+    std::deque<pinned_vec<uint32_t>> bv_runs;     // ... and, for the bit-vector paths, their runs (the sweeps keep theirs in `flat`)
     float timing[4] = {0, 0, 0, 0};               // [3]: device graph construction (malcs_gbuild.hip)
     uint64_t n_dev_built = 0;
     uint64_t tie_bytes = 0, tie_pairs = 0;        // bit-vector path: bytes of tie-bit rows its forward pass wrote (and its backward pass read), pairs
@@ -673,6 +676,7 @@ static int graph_batch(malcs_batch *b, const int64_t *shift, const int64_t *max_
     out->g.resize(N);
     std::vector<event_span> pair_events(N);
     std::deque<std::vector<event>> event_store;          // one buffer per chunk, alive until the graphs are built
+    std::deque<pinned_vec<uint32_t>> &bv_runs = out->bv_runs;   // the sorted runs of the pairs of a chunk the device built from its events (kept by the handle)
     std::vector<uint8_t> has_runs(N, 0);
 
     // [0]: long windows (workgroup of 512), [1]: windows below 4 096 rows at small distance (a wave each),
@@ -798,7 +802,8 @@ static int graph_batch(malcs_batch *b, const int64_t *shift, const int64_t *max_
 
     stages.lap("launch classes");
     pool_scoped<int64_t> d_shift(ctx);                                   // the shifts, for the graph kernels (the trim of a sink no edge reaches needs them)
-    if (shift && N && (!sweeps[0].pairs.empty() || !sweeps[1].pairs.empty())) {
+    const bool on_device = !(getenv("MALCS_GBUILD") && atoi(getenv("MALCS_GBUILD")) == 0);      // MALCS_GBUILD=0: host half only
+    if (shift && N && on_device && (!sweeps[0].pairs.empty() || !sweeps[1].pairs.empty() || !classes.empty())) {
         MALCS_HIP(d_shift.alloc(N));
         MALCS_HIP(hipMemcpyAsync(d_shift.p, shift, N * sizeof(int64_t), hipMemcpyHostToDevice, st));
         MALCS_HIP(malcs_sync(st));
@@ -808,7 +813,6 @@ static int graph_batch(malcs_batch *b, const int64_t *shift, const int64_t *max_
         if (S.pairs.empty()) continue;
         float ms[2] = {0, 0};
         gbuild_user user{b, out, shift, d_shift.p, &S.pairs};
-        const bool on_device = !(getenv("MALCS_GBUILD") && atoi(getenv("MALCS_GBUILD")) == 0);      // MALCS_GBUILD=0: host half only
         int rc = malcs_sweep_optimal_runs(b, shape == 1, S.pairs, dist.data(), 0, S.flat, S.first, ms, on_device ? gbuild_hook : nullptr, &user);
         if (rc) return rc;
         ms_fwd += ms[0]; ms_reach += ms[1];
@@ -855,6 +859,7 @@ static int graph_batch(malcs_batch *b, const int64_t *shift, const int64_t *max_
                 llcs.push_back((int32_t)((m + n - D) / 2));
             }
             const uint32_t cnt = (uint32_t)work.size();
+            stages.lap("  chunk lists");
             out->tie_bytes += used * 4ull; out->tie_pairs += cnt;
             if (d_work.alloc(cnt) || d_scoff.alloc(cnt) || d_scratch.alloc(used) || d_skip.alloc(cnt) ||
                 d_evcap.alloc(cnt) || d_evcnt.alloc(cnt) || d_evoff.alloc(cnt) || d_outoff.alloc(cnt) ||
@@ -868,6 +873,7 @@ static int graph_batch(malcs_batch *b, const int64_t *shift, const int64_t *max_
             MALCS_HIP(malcs_h2d(st, d_kmax.p, kmax.data(), cnt * 4ull));
             MALCS_HIP(malcs_h2d(st, d_rw.p, rw.data(), cnt * 4ull));
             MALCS_HIP(malcs_h2d(st, d_llcs.p, llcs.data(), cnt * 4ull));
+            stages.lap("  allocations, tables up");
             MALCS_HIP(hipEventRecord(ctx->ev0, st));
             int rc = malcs_graph_launch_forward(b, lc.W, lc.logL, lc.band, d_work.p, cnt, d_scratch.p, d_scoff.p,
                                                 d_kmin.p, d_kmax.p, d_rw.p, d_fdist.p);
@@ -879,6 +885,7 @@ static int graph_batch(malcs_batch *b, const int64_t *shift, const int64_t *max_
             float ms = 0;
             MALCS_HIP(hipEventElapsedTime(&ms, ctx->ev0, ctx->ev1));
             ms_fwd += ms;
+            stages.lap("  forward");
 
             std::vector<uint8_t> skip(cnt, 0);
             std::vector<uint32_t> ev_cap(cnt);
@@ -911,6 +918,7 @@ static int graph_batch(malcs_batch *b, const int64_t *shift, const int64_t *max_
                 MALCS_HIP(malcs_sync(st));
                 MALCS_HIP(hipEventElapsedTime(&ms, ctx->ev1, ctx->ev2));
                 ms_reach += ms;
+                stages.lap("  reach (+ event buffers)");
                 bool overflow = false;
                 for (uint32_t s = 0; s < cnt; s++) if (ev_cnt[s] > ev_cap[s]) overflow = true;
                 if (overflow) {
@@ -927,11 +935,68 @@ static int graph_batch(malcs_batch *b, const int64_t *shift, const int64_t *max_
                 MALCS_HIP(malcs_h2d(st, d_outoff.p, out_off.data(), cnt * 8ull));
                 rc = malcs_graph_launch_compact(ctx, d_events.p, d_evoff.p, d_evcnt.p, d_outoff.p, cnt, d_packed.p);
                 if (rc) return rc;
-                event_store.emplace_back(packed);
-                std::vector<event> &host_ev = event_store.back();
-                if (packed) MALCS_HIP(malcs_d2h(st, host_ev.data(), d_packed.p, packed * sizeof(event)));
-                MALCS_HIP(malcs_sync(st));
-                for (uint32_t s = 0; s < cnt; s++) { pair_events[work[s]].p = host_ev.data() + out_off[s]; pair_events[work[s]].n = ev_cnt[s]; }
+                stages.lap("  compaction queued");
+                if (on_device && packed) {
+                    // The events become runs on the device (k_events_to_runs) and the graph kernels take it from there, as
+                    // they do behind the sweeps; what they give up (more than 1 024 runs, events that do not pair up, full
+                    // buffers) stays with the host half below, which has the events.
+                    std::vector<uint64_t> run_off(cnt);
+                    std::vector<uint32_t> run_cnt(cnt), e2r[2];
+                    uint64_t runs_total = 0;
+                    for (uint32_t s = 0; s < cnt; s++) {
+                        const uint32_t E = ev_cnt[s];
+                        const bool fits = E >= 2 && !(E & 1u) && E <= 2048u;
+                        run_off[s] = runs_total; run_cnt[s] = fits ? E / 2u : 0u;
+                        runs_total += run_cnt[s];
+                        if (fits) e2r[E <= 128u ? 0 : 1].push_back(s);
+                    }
+                    if (runs_total) {
+                        dev_buf<uint4> d_runs(b->ctx);
+                        dev_buf<uint64_t> d_runoff(b->ctx);
+                        dev_buf<uint32_t> d_runcnt(b->ctx), d_e2r(b->ctx);
+                        if (d_runs.alloc(runs_total) || d_runoff.alloc(cnt) || d_runcnt.alloc(cnt) || d_e2r.alloc(cnt)) {
+                            malcs_set_error("device allocation failed (%llu runs)", (unsigned long long)runs_total); return MALCS_ERR_NOMEM;
+                        }
+                        std::vector<uint32_t> slots(e2r[0]);
+                        slots.insert(slots.end(), e2r[1].begin(), e2r[1].end());
+                        MALCS_HIP(malcs_h2d(st, d_runoff.p, run_off.data(), cnt * 8ull));
+                        MALCS_HIP(malcs_h2d(st, d_e2r.p, slots.data(), slots.size() * 4ull));
+                        MALCS_HIP(hipMemsetAsync(d_runcnt.p, 0, cnt * 4ull, st));
+                        rc = malcs_gbuild_events_to_runs(ctx, 0, d_packed.p, d_outoff.p, d_evcnt.p, d_e2r.p, (uint32_t)e2r[0].size(), d_runs.p, d_runoff.p, d_runcnt.p);
+                        if (!rc) rc = malcs_gbuild_events_to_runs(ctx, 1, d_packed.p, d_outoff.p, d_evcnt.p, d_e2r.p + e2r[0].size(), (uint32_t)e2r[1].size(),
+                                                                  d_runs.p, d_runoff.p, d_runcnt.p);
+                        if (rc) return rc;
+                        MALCS_HIP(malcs_sync(st));                               // (`slots` and `run_off` are locals the copies read)
+                        gbuild_user user{b, out, shift, d_shift.p, nullptr};
+                        const malcs_sweep_chunk chunk{d_runs.p, d_runoff.p, d_runcnt.p, d_work.p, cnt, work.data(), run_cnt.data(), run_off.data(), nullptr};
+                        rc = gbuild_hook(&user, chunk);
+                        if (rc) return rc;
+                        // the runs, sorted by the graph kernels, for the handle (runs(i)) of the pairs that were built there
+                        bv_runs.emplace_back();
+                        pinned_vec<uint32_t> &flat = bv_runs.back();
+                        flat.resize((size_t)runs_total * 4);
+                        MALCS_HIP(hipMemcpyAsync(flat.data(), d_runs.p, runs_total * 16ull, hipMemcpyDeviceToHost, st));
+                        MALCS_HIP(malcs_sync(st));
+                        for (uint32_t s = 0; s < cnt; s++) {
+                            pair_graph &G = out->g[work[s]];
+                            if (!G.dev_built) continue;
+                            G.dev_runs = flat.data() + 4 * run_off[s];
+                            G.dev_n_runs = (int64_t)run_cnt[s];
+                        }
+                    }
+                }
+                stages.lap("  runs and graphs on the device");
+                // the events come home for the pairs the device has not built (67 MB per 100 000 C2 pairs otherwise, for nothing)
+                bool wanted = false;
+                for (uint32_t s = 0; s < cnt && !wanted; s++) wanted = !out->g[work[s]].dev_built;
+                if (wanted) {
+                    event_store.emplace_back(packed);
+                    std::vector<event> &host_ev = event_store.back();
+                    if (packed) MALCS_HIP(malcs_d2h(st, host_ev.data(), d_packed.p, packed * sizeof(event)));
+                    MALCS_HIP(malcs_sync(st));
+                    for (uint32_t s = 0; s < cnt; s++) { pair_events[work[s]].p = host_ev.data() + out_off[s]; pair_events[work[s]].n = ev_cnt[s]; }
+                }
+                stages.lap("  events home");
                 break;
             }
         }
@@ -968,10 +1033,12 @@ static int graph_batch(malcs_batch *b, const int64_t *shift, const int64_t *max_
             if (G.status != MALCS_PAIR_OK) continue;
             const int64_t m = b->a_len[i], n = b->b_len[i];
             if (G.dev_built) {                                           // all done on the device: point at what came home
-                const sweep_set &S = sweeps[has_runs[i] - 2];
-                const uint64_t s = sweep_slot[i];
-                G.dev_runs = S.flat.data() + 4 * S.first[s];
-                G.dev_n_runs = (int64_t)(S.first[s + 1] - S.first[s]);
+                if (has_runs[i] >= 2) {                                  // (the bit-vector chunks have set theirs)
+                    const sweep_set &S = sweeps[has_runs[i] - 2];
+                    const uint64_t s = sweep_slot[i];
+                    G.dev_runs = S.flat.data() + 4 * S.first[s];
+                    G.dev_n_runs = (int64_t)(S.first[s + 1] - S.first[s]);
+                }
                 G.n_levels = (m + n - G.distance) / 2;
                 continue;
             }

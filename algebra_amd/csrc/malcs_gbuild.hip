@@ -113,6 +113,52 @@ k_graph_build(uint4 *__restrict__ runs, const uint64_t *__restrict__ run_off, co
     (void)bcast;
 }
 
+// ---- the bit-vector kernels' events -> runs ---------------------------------------------------------------------
+// k_lcs_reach leaves, per pair, the cells where a run of optimal matches starts (kind 1) and ends (kind 0), in the order
+// it met them.  Starts and ends alternate along every diagonal (malcs_build.cpp: runs_from_events): one wave per pair
+// ranks its events by (diagonal, row, start before end) with the counting the graph kernel uses for its runs, pairs
+// neighbours in that order into {row, col, length, level} and leaves the pair's runs where k_graph_build expects
+// them.  Events that do not pair up give a count of 0: the pair stays with the host half, which reports the error.
+template <int ECAP>
+__global__ void __launch_bounds__(64)
+k_events_to_runs(const uint4 *__restrict__ events, const uint64_t *__restrict__ ev_off, const uint32_t *__restrict__ ev_cnt,
+                 const uint32_t *__restrict__ slots, uint32_t n_slots, uint4 *__restrict__ runs, const uint64_t *__restrict__ run_off,
+                 uint32_t *__restrict__ run_cnt)
+{
+    __shared__ uint64_t key[ECAP];
+    __shared__ uint4 sorted[ECAP];
+    __shared__ uint32_t bad;
+    if (blockIdx.x >= n_slots) return;
+    const uint32_t slot = slots[blockIdx.x], lane = threadIdx.x;
+    const uint32_t E = ev_cnt[slot];
+    if (lane == 0) bad = (E & 1u) || E > (uint32_t)ECAP ? 1u : 0u;
+    __syncthreads();
+    if (bad) { if (lane == 0) run_cnt[slot] = 0u; return; }
+    const uint4 *mine = events + ev_off[slot];
+    for (uint32_t i = lane; i < E; i += 64) {
+        const uint4 e = mine[i];                                         // row, col, level, kind
+        const uint64_t diag = (uint64_t)(int64_t)((int64_t)e.y - (int64_t)e.x + 0x40000000ll);
+        key[i] = (diag << 33) | ((uint64_t)e.x << 1) | (uint64_t)(1u - (e.w & 1u));
+    }
+    __syncthreads();
+    for (uint32_t i = lane; i < E; i += 64) {
+        const uint64_t a = key[i];
+        uint32_t rank = 0;
+        for (uint32_t j = 0; j < E; j++) rank += (key[j] < a || (key[j] == a && j < i)) ? 1u : 0u;
+        sorted[rank] = mine[i];
+    }
+    __syncthreads();
+    uint4 *out = runs + run_off[slot];
+    for (uint32_t i = lane; i < E / 2u; i += 64) {
+        const uint4 s = sorted[2 * i], e = sorted[2 * i + 1];
+        const bool ok = s.w == 1u && e.w == 0u && (int64_t)s.y - (int64_t)s.x == (int64_t)e.y - (int64_t)e.x && e.x >= s.x;
+        if (!ok) atomicOr(&bad, 1u);
+        out[i] = make_uint4(s.x, s.y, e.x - s.x + 1u, e.z);
+    }
+    __syncthreads();
+    if (lane == 0) run_cnt[slot] = bad ? 0u : E / 2u;
+}
+
 }  // namespace
 
 int malcs_gbuild_pair_out_words() { return PAIR_OUT; }
@@ -139,6 +185,18 @@ int malcs_gbuild_launch(malcs_ctx *ctx, int kind, uint4 *d_runs, const uint64_t 
         hipLaunchKernelGGL((k_graph_build<1024, false, 1, 1, 1>), dim3(n_slots), dim3(64), 0, ctx->stream, d_runs, d_run_off, d_run_cnt,
                            d_pids, d_slots, n_slots, d_a_len, d_b_len, d_dist, d_shift, d_scratch, d_scratch_off, d_out_words,
                            (unsigned long long)out_cap, d_out_cursor, d_pair_out);
+    MALCS_HIP(hipGetLastError());
+    return MALCS_OK;
+}
+
+// kind 0: at most 128 events per pair, kind 1: at most 2 048 (= the 1 024 runs the graph kernels take)
+int malcs_gbuild_events_to_runs(malcs_ctx *ctx, int kind, const void *d_events, const uint64_t *d_ev_off, const uint32_t *d_ev_cnt,
+                                const uint32_t *d_slots, uint32_t n_slots, uint4 *d_runs, const uint64_t *d_run_off, uint32_t *d_run_cnt)
+{
+    if (!n_slots) return MALCS_OK;
+    const uint4 *ev = static_cast<const uint4 *>(d_events);
+    if (kind == 0) hipLaunchKernelGGL((k_events_to_runs<128>), dim3(n_slots), dim3(64), 0, ctx->stream, ev, d_ev_off, d_ev_cnt, d_slots, n_slots, d_runs, d_run_off, d_run_cnt);
+    else hipLaunchKernelGGL((k_events_to_runs<2048>), dim3(n_slots), dim3(64), 0, ctx->stream, ev, d_ev_off, d_ev_cnt, d_slots, n_slots, d_runs, d_run_off, d_run_cnt);
     MALCS_HIP(hipGetLastError());
     return MALCS_OK;
 }

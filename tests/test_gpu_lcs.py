@@ -752,17 +752,22 @@ def test_graph_long_windows_any_alphabet(native, alphabet, path, monkeypatch):
     res.close()
 
 
-def test_graphs_built_on_the_device_match_the_host_half(native, monkeypatch):
+@pytest.mark.parametrize("path", ["sweep", "bit-vector"])
+def test_graphs_built_on_the_device_match_the_host_half(native, path, monkeypatch):
     """Kernel family 2c (malcs_gbuild.hip): ordering of the runs, dominance edges, splits, trimming and numbering on
     the device against the host half of the library (same pairs, MALCS_GBUILD=0) and against the oracle.  6 000 pairs:
     beyond 4 096 graphs of at most 32 runs the kernels run in four groups whose words come home on the second stream
-    while the next group is built, followed by the group of the graphs with more runs."""
+    while the next group is built, followed by the group of the graphs with more runs.  Both device paths feed it: the
+    sweeps their runs, the bit-vector kernels their events through k_events_to_runs."""
     from oracle import oracle as O
     data = gen.c2_batch(6000, seed=31)
     shifts = np.arange(6000, dtype=np.int64) % 7
     ctx = native.default_context()
+    if path == "bit-vector":
+        monkeypatch.setenv("MALCS_SWEEP_DMAX", "-1")
     batch = native.Batch(ctx, *data, 4)
     dev = batch.graphs(shifts)
+    assert (dev.tie_pairs == 6000) == (path == "bit-vector")
     monkeypatch.setenv("MALCS_GBUILD", "0")
     host = batch.graphs(shifts)
     monkeypatch.delenv("MALCS_GBUILD")
