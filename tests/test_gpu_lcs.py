@@ -693,6 +693,27 @@ def test_large_from_sequence(native, idx, path, monkeypatch):
     assert digest(got) == rec["graph_sha256"]
 
 
+@pytest.mark.parametrize("path", ["sweep", "band"])
+def test_c3_and_c5_i_at_the_config_count(native, path, monkeypatch):
+    """BASELINE config 3 at its own count (16 pairs of 10 kb tandem-repeat windows, the generator and seeds bench.py
+    times) and config 5 (i) at its (4 sparse 1 Mb pairs), as ONE batch each, on both device paths.  The reference's own
+    outputs pin two of the C3 pairs and one of the 1 Mb pairs (test_large_from_sequence); the others are checked against
+    the C oracle, which those fixtures pin in turn: parity with the reference itself is unpinned for them."""
+    from oracle import oracle as O
+    from algebra_amd.lcs import LCSgraph
+    use_path(monkeypatch, path)
+    c3 = [gen.tandem_pair(np.random.RandomState(300 + s), 10000, 20) for s in range(16)]
+    c5 = [gen.large_pair({"kind": "few", "seed": 50 + i, "length": 1000000, "events": 20}) for i in range(4)]
+    for pairs in (c3, c5):
+        graphs = LCSgraph.batch(pairs)
+        for (a, b), graph in zip(pairs, graphs):
+            ref = O.lcs_graph(a, b)
+            assert graph.distance == ref.distance
+            assert (graph.supremal.start, graph.supremal.end) == tuple(ref.supremal[:2])
+            result, index = graph._result
+            assert np.array_equal(result.nodes(index), ref.nodes) and np.array_equal(result.edges(index), ref.edges)
+
+
 def test_graph_size_limit_is_loud(native):
     from algebra_amd.lcs import LCSgraph
     rs = np.random.RandomState(9)
