@@ -26,6 +26,22 @@ def stats(path):
              f"{'calls':>6} {'total_ns':>14} {'avg_ns':>12} {'min_ns':>10} {'max_ns':>10} {'pct':>6}  kernel"]
     for name, n, tot, avg, mn, mx in rows:
         lines.append(f"{n:6d} {tot:14.0f} {avg:12.1f} {mn:10.0f} {mx:10.0f} {100*tot/total:6.2f}  {short(name)}")
+    # the window kernel by what ran before it on the device: right behind the layout (a step of the bench) or behind its
+    # own kind (the replays the roofline's kernel_ms is measured on)
+    try:
+        seq = db_of(path).execute("select name, duration from kernels order by start").fetchall()
+    except sqlite3.Error:
+        seq = []
+    split = {}
+    for (prev, _), (name, dur) in zip(seq, seq[1:]):
+        if "k_llcs_diag" in name:
+            key = "behind k_diag_layout (in a step)" if "k_diag_layout" in prev else "behind its own kind (replayed)" if "k_llcs_" in prev else "behind anything else"
+            split.setdefault((short(name), key), []).append(dur)
+    if split:
+        lines.append("# the window kernel by its predecessor on the device")
+        for (name, key), d in sorted(split.items()):
+            d.sort()
+            lines.append(f"{len(d):6d} {sum(d):14.0f} {sum(d)/len(d):12.1f} {d[0]:10.0f} {d[-1]:10.0f} {'':>6}  {name} {key}; median {d[len(d)//2]:.0f}")
     return "\n".join(lines) + "\n"
 
 
