@@ -850,7 +850,8 @@ int malcs_diag_setup(malcs_batch *b, int nlw, const std::vector<uint32_t> &pairs
     // known here, taken off again on the device.  All sub-pairs run in ONE full-matrix class, the narrowest their longest
     // allows -- the sample is a few hundred waves that run side by side, so its time is the time of one wave: columns x limbs.
     std::vector<uint32_t> sample;                            // a_off, a_len, b_off, b_len, list (SAMPLE_SLOTS n_sample each); n_sample corrections
-    uint32_t n_sample = 0;
+    uint32_t n_sample = 0, longest_whole = 0;
+    std::vector<uint32_t> sample_tab;                        // the same pairs whole {a_off, a_len, b_off, b_len} for the one-lane sample, which cuts them on the device
     int sW = 1, sL = 1;
     const char *env_half = getenv("MALCS_DIAG_HALF");
     const bool forced = env_half && *env_half;
@@ -864,6 +865,8 @@ int malcs_diag_setup(malcs_batch *b, int nlw, const std::vector<uint32_t> &pairs
         for (size_t i = stride / 2; i < count && k < n_sample; i += stride, k++) {
             const uint32_t pid = pairs[i];
             const uint32_t la = b->a_len[pid], lb = b->b_len[pid];
+            sample_tab.insert(sample_tab.end(), {b->a_off[pid], la, b->b_off[pid], lb});
+            longest_whole = std::max(longest_whole, std::max(la, lb));
             uint32_t ca = 0, cb = 0;                             // where the part starts
             for (uint32_t part = 0; part < SAMPLE_PARTS; part++) {
                 uint32_t ea = la, eb = lb;                       // ... and ends
@@ -915,7 +918,8 @@ int malcs_diag_setup(malcs_batch *b, int nlw, const std::vector<uint32_t> &pairs
     const size_t at_count = carve(keep, 2 * ncls);                         // two sets, used by alternate launches
     const size_t at_jbuf = carve(keep, (size_t)(cut_possible ? n_tiles : 1u) * JOIN_WORDS * 128u);   // JOIN_WORDS 64-bit words per lane of a cut tile
     const size_t at_stats = carve(keep, PS_FIELDS);
-    const size_t at_sample = carve(keep, (size_t)(5 * SAMPLE_SLOTS + 1) * n_sample + 64), at_sdist = carve(keep, (size_t)SAMPLE_SLOTS * n_sample + 64);
+    const size_t at_sample = carve(keep, (size_t)(5 * SAMPLE_SLOTS + 1) * n_sample + 64), at_sdist = carve(keep, (size_t)SAMPLE_SLOTS * n_sample + 64),
+                 at_stab = carve(keep, (size_t)4 * n_sample + 64);
     MALCS_HIP(malcs_pool_alloc(ctx, (void **)&d.d_rows, keep * sizeof(uint32_t)));
     (void)at_rows;                                                         // the rows come first: d_rows is the allocation
     uint32_t *const base = d.d_rows;
@@ -925,7 +929,7 @@ int malcs_diag_setup(malcs_batch *b, int nlw, const std::vector<uint32_t> &pairs
     d.d_piece_place = d.d_piece_join + n_launch; d.d_lay_off = d.d_piece_place + n_launch; d.d_lay_info = d.d_lay_off + n_launch; d.d_lay_it = d.d_lay_info + n_launch;
     d.d_join_buf = base + at_jbuf; d.d_stats = base + at_stats;
     d.d_retry_list = base + at_list; d.d_retry_first = base + at_first; d.d_retry_cap = base + at_cap; d.d_retry_count = base + at_count;
-    d.d_sample = base + at_sample; d.d_sample_dist = reinterpret_cast<int32_t *>(base + at_sdist);
+    d.d_sample = base + at_sample; d.d_sample_dist = reinterpret_cast<int32_t *>(base + at_sdist); d.d_sample_tab = base + at_stab;
     // what starts at zero: the two sets of histogram, cursors and column sums (every plan zeroes the other set for the
     // next), the join buffer (every launch leaves its slots at zero), the statistics
     MALCS_HIP(hipMemsetAsync(d.d_sets, 0, 2 * (size_t)set_words * sizeof(uint32_t), st));
@@ -940,11 +944,17 @@ int malcs_diag_setup(malcs_batch *b, int nlw, const std::vector<uint32_t> &pairs
         MALCS_HIP(malcs_h2d(st, d.d_sample, sample.data(), sample.size() * sizeof(uint32_t)));
         const uint32_t subs = SAMPLE_SLOTS * n_sample;
         MALCS_HIP(malcs_h2d(st, d.d_sample + (size_t)(5 * SAMPLE_SLOTS + 1) * n_sample, &subs, sizeof(uint32_t)));
+        MALCS_HIP(malcs_h2d(st, d.d_sample_tab, sample_tab.data(), (size_t)4 * n_sample * sizeof(uint32_t)));
     }
     MALCS_HIP(malcs_sync(st));                                             // the sources are locals (copies beyond the staging buffer read them directly)
     d.nlw = nlw; d.T = malcs_diag_threshold(nlw); d.n_tiles = n_tiles; d.n_pairs = count; d.n_launch = n_launch;
     d.max_len = max_len; d.HB = HB; d.can_half = can_half; d.cut_possible = cut_possible; d.n_sample = n_sample;
     d.sample_W = sW; d.sample_L = sL; d.rows_cap = rows_cap; d.parity = 0; d.planned = false; d.plan_parity = 0;
+    // one lane per part of a pair (llcs_band32_lane) where the parts are short enough for one lane's time; MALCS_SAMPLE_WAVE=1
+    // keeps the full-matrix wave over the host's sub-pairs (round 2's sample; also what longer sequences get)
+    d.sample_log_parts = 2;
+    while ((LANE_PART_SYMS << d.sample_log_parts) < longest_whole) d.sample_log_parts++;
+    d.sample_lanes = n_sample && NP == 2 && (1u << d.sample_log_parts) <= LANE_MAX_PARTS && !(getenv("MALCS_SAMPLE_WAVE") && atoi(getenv("MALCS_SAMPLE_WAVE")) != 0);
     d.sample_inside = n_sample && sW == 1 && sL > 1 && sL <= 64 / (int)SAMPLE_SLOTS;   // (the places of a pair in one wave)                       // the sample as workgroups of the plan's first launch
     return MALCS_OK;
 }
@@ -963,7 +973,7 @@ int malcs_diag_plan(malcs_batch *b)
     A.parity = d.plan_parity;
     A.sitem = d.d_sitem; A.pub = d.d_pub; A.lay_off = d.d_lay_off; A.lay_info = d.d_lay_info; A.lay_it = d.d_lay_it; A.piece_off = d.d_piece_off; A.piece_info = d.d_piece_info;
     A.piece_join = d.d_piece_join; A.piece_place = d.d_piece_place; A.retry_count = d.d_retry_count; A.stats = d.d_stats; A.rows = d.d_rows;
-    A.sample = d.d_sample; A.sample_dist = d.d_sample_dist;
+    A.sample = d.d_sample; A.sample_dist = d.d_sample_dist; A.sample_tab = reinterpret_cast<const uint4 *>(d.d_sample_tab); A.sample_log_parts = (uint32_t)d.sample_log_parts;
     A.HB = HB; A.count = count; A.n_tiles = d.n_tiles; A.n_launch = d.n_launch; A.S = (uint32_t)std::max(1, ctx->prop.multiProcessorCount) * 4u;
     A.NP = NP; A.n_sample = d.n_sample; A.n_retry_words = 2u * (uint32_t)std::max<size_t>(d.retry.size(), 1);
     A.min_rows = 32u * (2u * (uint32_t)d.nlw + 2u);
@@ -982,8 +992,8 @@ int malcs_diag_plan(malcs_batch *b)
     while ((1 << logL) < d.sample_L) logL++;
     A.sample_logL = logL;
     const uint32_t n2 = SAMPLE_SLOTS * d.n_sample, ppw = 64u / (uint32_t)std::max(d.sample_L, 1);
-    A.sample_blocks = d.sample_inside ? ((n2 + ppw - 1u) / ppw + 3u) / 4u : 0u;
-    if (d.n_sample && !d.sample_inside) {
+    A.sample_blocks = d.sample_lanes ? (d.n_sample + (256u >> d.sample_log_parts) - 1u) / (256u >> d.sample_log_parts) : d.sample_inside ? ((n2 + ppw - 1u) / ppw + 3u) / 4u : 0u;
+    if (d.n_sample && !d.sample_inside && !d.sample_lanes) {
         // sub-pairs beyond 4 096 rows (sequences beyond 8 kb): the sample as a launch of its own, in front of the plan
         uint32_t *sa_off = d.d_sample, *sa_len = sa_off + n2, *sb_off = sa_len + n2, *sb_len = sb_off + n2, *list = sb_len + n2, *cnt = list + n2 + d.n_sample;
         const int rc = malcs_dist_launch_list(st, b->n_planes, d.sample_W, d.sample_L, b->d_planes, sa_off, sa_len, sb_off, sb_len,
@@ -995,11 +1005,12 @@ int malcs_diag_plan(malcs_batch *b)
     const dim3 g_ends(A.sample_blocks + (count + 255u) / 256u), b256(256);
     const size_t hist_lds = (size_t)H2 * sizeof(uint32_t);
     switch (NP) {
-    case 2: if (d.sample_inside) hipLaunchKernelGGL((k_plan_ends<2, true>), g_ends, b256, hist_lds, st, A);
-            else hipLaunchKernelGGL((k_plan_ends<2, false>), g_ends, b256, hist_lds, st, A);
+    case 2: if (d.sample_lanes) hipLaunchKernelGGL((k_plan_ends<2, 2>), g_ends, b256, hist_lds, st, A);
+            else if (d.sample_inside) hipLaunchKernelGGL((k_plan_ends<2, 1>), g_ends, b256, hist_lds, st, A);
+            else hipLaunchKernelGGL((k_plan_ends<2, 0>), g_ends, b256, hist_lds, st, A);
             break;
-    case 3: hipLaunchKernelGGL((k_plan_ends<3, false>), g_ends, b256, hist_lds, st, A); break;
-    case 4: hipLaunchKernelGGL((k_plan_ends<4, false>), g_ends, b256, hist_lds, st, A); break;
+    case 3: hipLaunchKernelGGL((k_plan_ends<3, 0>), g_ends, b256, hist_lds, st, A); break;
+    case 4: hipLaunchKernelGGL((k_plan_ends<4, 0>), g_ends, b256, hist_lds, st, A); break;
     }
     MALCS_HIP(hipGetLastError());
     hipLaunchKernelGGL(k_plan_scatter, dim3((count + 1023u) / 1024u + 1u), dim3(1024), 3 * hist_lds, st, A);   // (+ 1: the workgroup that publishes the plan)

@@ -181,6 +181,9 @@ struct diag_plan {
     uint32_t *d_join_buf = nullptr;
     uint32_t *d_stats = nullptr;         // what the last plan decided (plan_stats)
     uint32_t *d_sample = nullptr;        // static: a_off, a_len, b_off, b_len, list of the sample's sub-pairs, a correction per sampled pair, the count
+    uint32_t *d_sample_tab = nullptr;    // static: the sampled pairs {a_off, a_len, b_off, b_len} (the one-lane sample cuts them itself)
+    bool sample_lanes = false;           // the sample runs one lane per part of a pair (llcs_band32_lane) ...
+    int sample_log_parts = 0;            // ... of which a pair has 1 << this many
     int32_t *d_sample_dist = nullptr;    // the sub-pairs' distances (written by every plan)
     uint32_t *d_retry_list = nullptr, *d_retry_first = nullptr, *d_retry_cap = nullptr, *d_retry_count = nullptr;
     std::vector<diag_retry> retry;

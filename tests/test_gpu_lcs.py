@@ -288,6 +288,30 @@ def test_edit_distance_two_limb_mode(native, half, monkeypatch):
     assert np.array_equal(got, O.edit_distance_batch(*data))
 
 
+@pytest.mark.parametrize("wave", ["", "1"])
+def test_sample_estimate_bounds_the_distances(native, wave, monkeypatch):
+    """The sample that picks the window class's mode (malcs_plan.inc: one lane per part of a pair, cuts probed on the
+    device; MALCS_SAMPLE_WAVE=1: the full-matrix wave over sub-pairs the host cut, which sequences beyond 4 096 symbols
+    always get) estimates a pair's distance from above.  Its mean must lie between the batch's own mean (less the
+    sampling error of 1 000 pairs) and a third more; the distances themselves are the oracle's in every case."""
+    from oracle import oracle as O
+    if wave:
+        monkeypatch.setenv("MALCS_SAMPLE_WAVE", wave)
+    for pairs, length, p, seed in [(8000, 330, 0.01, 31), (8000, 1000, 0.01, 32), (6000, 1900, 0.005, 33), (5000, 4000, 0.002, 34),
+                                   (4200, 6000, 0.001, 35), (8000, 700, 0.03, 36)]:
+        data = gen.c2_batch(pairs, seed=seed, length=length, p=p)
+        batch = native.Batch(native.default_context(), *data, n_symbols=4)
+        info = batch.plan_info()
+        got = batch.distances()
+        batch.close()
+        ref = O.edit_distance_batch(*data)
+        assert np.array_equal(got, ref), (length, p)
+        if info["window_tiles"] == 0:
+            continue
+        mean, est = float(ref.mean()), info["sample_mean_x16"] / 16.0
+        assert mean - 4.0 * float(ref.std()) / 30.0 - 0.1 <= est <= 1.34 * mean + 2.0, (length, p, mean, est, info)
+
+
 @pytest.mark.parametrize("pairs,length,p,half", [(100000, 1000, 0.01, ""), (6000, 1000, 0.01, ""), (5000, 700, 0.04, ""), (7000, 460, 0.02, "1"),
                                                  (3000, 1500, 0.01, "1"), (300000, 330, 0.02, "")])
 def test_window_plan_made_on_the_device(native, pairs, length, p, half, monkeypatch):
