@@ -484,22 +484,23 @@ k_llcs_diag(const uint32_t *__restrict__ rows, const uint32_t *__restrict__ piec
             uint32_t *__restrict__ retry_list, const uint32_t *__restrict__ retry_first,
             const uint32_t *__restrict__ retry_cap, uint32_t *__restrict__ retry_count,
             uint32_t *__restrict__ retry_count_next, uint32_t n_classes,
-            uint32_t *__restrict__ join_buf, unsigned long long *__restrict__ stamps)
+            uint32_t *__restrict__ join_buf, unsigned long long *__restrict__ stamps, uint32_t pad)
 {
     constexpr int T = 32 * NLW - 32;
     // dev (MALCS_DIAG_STAMPS): the 100 MHz wall clock at four points of every wave + where it runs
     auto stamp = [&](int k) {
         if (stamps > reinterpret_cast<unsigned long long *>(1) && threadIdx.x == 0) {
             unsigned long long t = wall_clock64();
-            if (k == 0) { uint32_t hw, xcc; asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hw)); asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc)); stamps[blockIdx.x * 6ull + 4] = hw; stamps[blockIdx.x * 6ull + 5] = (xcc & 15u) | ((unsigned long long)piece_info[blockIdx.x] << 8); }
-            stamps[blockIdx.x * 6ull + k] = t;
+            if (k == 0) { uint32_t hw, xcc; asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hw)); asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc)); stamps[(blockIdx.x - pad) * 6ull + 4] = hw; stamps[(blockIdx.x - pad) * 6ull + 5] = (xcc & 15u) | ((unsigned long long)piece_info[blockIdx.x - pad] << 8); }
+            stamps[(blockIdx.x - pad) * 6ull + k] = t;
         }
     };
+    if (blockIdx.x < pad) return;                      // (see malcs_diag_launch: workgroups that only take the first turn of the hardware's round)
     stamp(0);
     // the counters of the NEXT launch start at zero: nothing in flight reads or writes that set now
-    if (blockIdx.x == 0 && threadIdx.x < n_classes) retry_count_next[threadIdx.x] = 0u;
+    if (blockIdx.x == pad && threadIdx.x < n_classes) retry_count_next[threadIdx.x] = 0u;
     const unsigned lane = threadIdx.x;
-    const uint32_t tile = blockIdx.x;
+    const uint32_t tile = blockIdx.x - pad;
     // where the piece's rows are and what it is: two scalar loads side by side (the compiler makes them vector loads,
     // at twice the latency, and everything a wave does waits for them)
     // (the slot of the join buffer too: read after the loop, it was two more trips to memory in a row -- the kernel
@@ -772,7 +773,7 @@ k_llcs_diag(const uint32_t *__restrict__ rows, const uint32_t *__restrict__ piec
 }
 
 typedef void (*diag_kernel_t)(const uint32_t *, const uint32_t *, const uint32_t *, const uint32_t *, int32_t *, uint32_t *,
-                              const uint32_t *, const uint32_t *, uint32_t *, uint32_t *, uint32_t, uint32_t *, unsigned long long *);
+                              const uint32_t *, const uint32_t *, uint32_t *, uint32_t *, uint32_t, uint32_t *, unsigned long long *, uint32_t);
 template <int NP>
 diag_kernel_t pick_diag(int nlw)
 {
@@ -1093,20 +1094,40 @@ int malcs_diag_launch(malcs_batch *b, bool advance, hipEvent_t start, hipEvent_t
     if (getenv("MALCS_DIAG_NORETRY")) stamps = reinterpret_cast<unsigned long long *>(1);
     else
 #endif
-    if (stamp_path && *stamp_path) { MALCS_HIP(hipMalloc((void **)&stamps, (size_t)d.n_launch * 48)); MALCS_HIP(hipMemsetAsync(stamps, 0, (size_t)d.n_launch * 48, st)); }
+    // (the buffer is made by the first launch that asks and kept: a launch right behind a plan must not wait for an allocation)
+    static unsigned long long *stamp_buf = nullptr;
+    static size_t stamp_cap = 0;
+    if (stamp_path && *stamp_path) {
+        if (stamp_cap < (size_t)d.n_launch * 48) {
+            MALCS_HIP(hipStreamSynchronize(st));
+            if (stamp_buf) MALCS_HIP(hipFree(stamp_buf));
+            stamp_cap = (size_t)d.n_launch * 48;
+            MALCS_HIP(hipMalloc((void **)&stamp_buf, stamp_cap));
+            MALCS_HIP(hipMemset(stamp_buf, 0, stamp_cap));
+        }
+        stamps = stamp_buf;
+    }
+    // The deal balances the blocks of the pieces w, w + S, w + 2 S, ... (S = SIMDs of the device), which is who shares a
+    // SIMD when the hardware hands one-wave workgroups out in turn.  It does right behind a launch of the same kind; right
+    // behind the layout (workgroups of eight waves) the first turn skips a quarter of every XCD's CUs and doubles up on
+    // the others: 92 SIMDs with four pieces, 38 with two, the busiest with 60 blocks instead of 44, the launch 3.5 us
+    // longer (tools/diag_in_step.py: per-wave time stamps and where every wave ran).  One workgroup per CU that returns
+    // at once, in front of the others in the same launch, takes that first turn: placement is then the deal's in every
+    // case (128 such workgroups: not quite; 256 ... 3 126: the same).  MALCS_DIAG_PAD=0 for the comparison.
+    uint32_t pad = (uint32_t)std::max(1, b->ctx->prop.multiProcessorCount);
+    if (const char *e = getenv("MALCS_DIAG_PAD")) pad = (uint32_t)std::max(0, atoi(e));
     if (start || stop)     // the dispatch's own time stamps (what a profiler reports as the kernel's duration)
-        hipExtLaunchKernelGGL(fn, dim3(d.n_launch), dim3(64), 0, st, start, stop, 0, (const uint32_t *)d.d_rows, (const uint32_t *)d.d_piece_off,
+        hipExtLaunchKernelGGL(fn, dim3(d.n_launch + pad), dim3(64), 0, st, start, stop, 0, (const uint32_t *)d.d_rows, (const uint32_t *)d.d_piece_off,
                               (const uint32_t *)d.d_piece_info, (const uint32_t *)d.d_piece_join, b->d_dist, d.d_retry_list,
-                              (const uint32_t *)d.d_retry_first, (const uint32_t *)d.d_retry_cap, cur, next, advance ? ncls : 0u, d.d_join_buf, stamps);
+                              (const uint32_t *)d.d_retry_first, (const uint32_t *)d.d_retry_cap, cur, next, advance ? ncls : 0u, d.d_join_buf, stamps, pad);
     else
-        hipLaunchKernelGGL(fn, dim3(d.n_launch), dim3(64), 0, st, d.d_rows, d.d_piece_off, d.d_piece_info, d.d_piece_join, b->d_dist,
-                           d.d_retry_list, d.d_retry_first, d.d_retry_cap, cur, next, advance ? ncls : 0u, d.d_join_buf, stamps);
+        hipLaunchKernelGGL(fn, dim3(d.n_launch + pad), dim3(64), 0, st, d.d_rows, d.d_piece_off, d.d_piece_info, d.d_piece_join, b->d_dist,
+                           d.d_retry_list, d.d_retry_first, d.d_retry_cap, cur, next, advance ? ncls : 0u, d.d_join_buf, stamps, pad);
     MALCS_HIP(hipGetLastError());
     if (stamps > reinterpret_cast<unsigned long long *>(1)) {
         std::vector<unsigned long long> host((size_t)d.n_launch * 6);
         MALCS_HIP(hipStreamSynchronize(st));
         MALCS_HIP(hipMemcpy(host.data(), stamps, host.size() * 8, hipMemcpyDeviceToHost));
-        MALCS_HIP(hipFree(stamps));
         if (FILE *f = fopen(stamp_path, "wb")) { fwrite(host.data(), 8, host.size(), f); fclose(f); }
     }
     return MALCS_OK;
