@@ -312,6 +312,8 @@ def main():
     ap.add_argument("--steps", type=int, default=1000)
     ap.add_argument("--warmup", type=int, default=20)
     ap.add_argument("--pairs", type=int, default=100000)
+    ap.add_argument("--in-flight", type=int, default=3, help="batches in flight per GPU, one stream (context) each: step i is batch "
+                                                             "i mod F; 1 = one stream, every step behind the one before")
     ap.add_argument("--preheat-ms", type=float, default=100.0, help="untimed steps before the warm-up, to bring the clocks up")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extra", action="store_true", help="skip the secondary configs (graphs, relation matrix)")
@@ -354,6 +356,16 @@ def main():
     syms, a_off, a_len, b_off, b_len = data
     cells = float((a_len.astype(np.float64) * b_len.astype(np.float64)).sum())
     batch = _native.Batch(ctx, syms, a_off, a_len, b_off, b_len, 4)
+    # A stream of batches: F of them are resident and in flight at a time, each on a stream (context) of its own, so
+    # that the plan of one (three short launches bound by trips to memory) runs beside the distance kernels of another
+    # (bound by the VALU).  Step i is one pass over batch i mod F; all K passes are done inside the timed region.
+    F = max(1, args.in_flight)
+    ctxs, batches, batch_cells = [ctx], [batch], [cells]
+    for k in range(1, F):
+        ctxs.append(_native.Context(local_rank))
+        more = gen.c2_batch(args.pairs, seed=2 + rank + 1000 * k)
+        batch_cells.append(float((more[2].astype(np.float64) * more[4].astype(np.float64)).sum()))
+        batches.append(_native.Batch(ctxs[k], *more, 4))
 
     def fence():
         torch.cuda.synchronize()
@@ -371,35 +383,48 @@ def main():
     # The card idles at low clocks and takes tens of milliseconds of work to leave them (a launch measured over 50 cold
     # repetitions is 12 % slower than over 1 000): `--preheat-ms` of untimed steps come before the W warm-up steps, so
     # that a short run (--steps 20) measures the same machine state as a long one.
-    def step():
-        batch.replan()                             # everything that depends on the sequences, queued on the device
-        batch.launch_distances()
+    def step(i=0):
+        b = batches[i % F]
+        b.replan()                                 # everything that depends on the sequences, queued on the device
+        b.launch_distances()
 
     t_heat = time.perf_counter()
     while (time.perf_counter() - t_heat) * 1e3 < args.preheat_ms:
-        for _ in range(20):
-            step()
-        ctx.sync()
-    for _ in range(args.warmup):
-        step()
+        for i in range(20):
+            step(i)
+        torch.cuda.synchronize()
+    for i in range(args.warmup):
+        step(i)
     fence()
     t0 = time.perf_counter()
-    for _ in range(args.steps):
-        step()
-    torch.cuda.synchronize()                       # this rank's K steps are done ...
+    for i in range(args.steps):
+        step(i)
+    torch.cuda.synchronize()                       # this rank's K steps are done (every stream of the device) ...
     elapsed = time.perf_counter() - t0
     fence()                                        # ... and the job is done when the slowest rank is: MAX below
+    cells_done = sum(batch_cells[i % F] for i in range(args.steps))      # what this rank's K steps computed
     if dist is not None:
         elapsed = all_max(elapsed)
-        c = torch.tensor([cells], dtype=torch.float64, device=reduce_device)
+        c = torch.tensor([cells_done], dtype=torch.float64, device=reduce_device)
         dist.all_reduce(c, op=dist.ReduceOp.SUM)
-        total_cells = float(c.item())
+        total_cells = float(c.item()) / args.steps
     else:
-        total_cells = cells
+        total_cells = cells_done / args.steps
+    # the same K steps on ONE stream (every step behind the one before): what the plan and the kernels cost in a row
+    one_ms = elapsed / args.steps * 1e3
+    if F > 1:
+        for _ in range(args.warmup):
+            step(0)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(args.steps):
+            step(0)
+        torch.cuda.synchronize()
+        one_ms = (time.perf_counter() - t0) / args.steps * 1e3
 
     # a checksum of the results so that a wrong kernel cannot hide behind a fast one
     d = batch.fetch_distances()
-    mean_distance = float(d.mean())
+    mean_distance = float(np.mean([b.fetch_distances().mean() for b in batches]))
 
     # dominant kernel: HIP events on the library's stream around `steps` launches of that kernel alone.
     # Its work is priced on the cells it computes: the window class evaluates 32 * limbs rows of every
@@ -431,10 +456,10 @@ def main():
         ctx.sync()
         plan_ms = (time.perf_counter() - t0) / launches * 1e3
         in_step = {"plan_ms": round(plan_ms, 4),
-                   "distance_kernels_ms": round(elapsed / args.steps * 1e3 - plan_ms, 4),
+                   "distance_kernels_ms": round(one_ms - plan_ms, 4),
                    "distance_kernels_replayed_ms": round(step_ms, 4),
                    "what": "plan_ms = the plan's three launches alone (same loop as the headline without the launch); distance_kernels_ms = "
-                           "ms_per_step - plan_ms = the window kernel + the retry list kernel as a step runs them; replayed: the same two over "
+                           "one_in_flight.ms - plan_ms = the window kernel + the retry list kernel as a step runs them; replayed: the same two over "
                            "the rows of a plan that is already there (the roofline's kernel_ms is the window kernel of those replays)"}
     else:
         in_step = None
@@ -575,11 +600,12 @@ def main():
             "ms_per_step": round(elapsed / args.steps * 1e3, 4),
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "u32", "data": "synthetic",
-            "config": {"workload": f"C2: {args.pairs} pairs/GPU, 1 kb reference windows, ~2% indels (seed 2+rank); resident in HBM "
+            "config": {"workload": f"C2: batches of {args.pairs} pairs/GPU, 1 kb reference windows, ~2% indels (seeds 2+rank+1000k); resident in HBM "
                                    "when a step starts: the packed bit planes (2 bit/base) and the per-pair offset / length "
-                                   "tables, nothing derived from the sequences; a step = the batch's plan on the device "
-                                   "(common ends, sort into tiles, sample, pieces, rows) + the distance kernels",
-                       "pairs_per_gpu": args.pairs,
+                                   "tables, nothing derived from the sequences; a step = one batch's plan on the device "
+                                   "(common ends, sort into tiles, sample, pieces, rows) + its distance kernels; "
+                                   f"{F} batch(es) in flight per GPU, a stream each (step i is batch i mod {F})",
+                       "pairs_per_gpu": args.pairs, "batches_in_flight": F,
                        "parallelism": f"independent pairs x {world} rank(s)", "device": name},
             "mean_distance": round(mean_distance, 3),
             "roofline": {"bound": "valu", "achieved": round(achieved, 2), "peak": round(PEAK_LANE_OPS / 1e12, 1),
@@ -594,6 +620,9 @@ def main():
             "plan": plan,
             "plan_inclusive": {"pairs_per_s": round(args.pairs * world * args.steps / elapsed, 1), "ms": round(elapsed / args.steps * 1e3, 4),
                                "what": "= the headline: per batch, plan on the device + launch, nothing copied back"},
+            "one_in_flight": {"pairs_per_s": round(args.pairs / (one_ms * 1e-3), 1), "ms": round(one_ms, 4),
+                              "what": "rank 0, the same steps on one stream, every step behind the one before (rounds 1-3's headline until "
+                                      "the batches went in flight side by side): the plan's three launches and the distance kernels in a row"},
             "resident_replay": {"pairs_per_s": round(args.pairs / replay_s, 1), "ms": round(step_ms, 4),
                                 "GCUPS": round(cells / replay_s / 1e9, 1),
                                 "what": "the distance kernels alone, replayed over the rows of a plan that is already there (HIP events, "
@@ -632,10 +661,11 @@ def main():
         os._exit(4 if hung else 3)
     if matrix_error is not None:
         sys.stderr.write(f"bench.py: relation matrix failed: {matrix_error}\n")
-        batch.close(); ctx.close()
+        for b in batches: b.close()
+        for c in ctxs: c.close()
         sys.exit(3)
-    batch.close()
-    ctx.close()
+    for b in batches: b.close()
+    for c in ctxs: c.close()
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()

@@ -288,6 +288,27 @@ def test_edit_distance_two_limb_mode(native, half, monkeypatch):
     assert np.array_equal(got, O.edit_distance_batch(*data))
 
 
+def test_batches_in_flight_on_streams_of_their_own(native):
+    """bench.py keeps three batches in flight, each on a context (= stream) of its own, so that one batch's plan runs
+    beside another's distance kernels.  Plans and launches queued in turn, many times over, without a wait in between:
+    every batch's distances are the oracle's, whatever the others were doing on the card at the time."""
+    from oracle import oracle as O
+    ctxs = [native.Context(0) for _ in range(3)]
+    datas = [gen.c2_batch(40000, seed=90 + k, length=(1000, 700, 1300)[k], p=(0.01, 0.02, 0.005)[k]) for k in range(3)]
+    batches = [native.Batch(c, *d, n_symbols=4) for c, d in zip(ctxs, datas)]
+    for i in range(60):
+        b = batches[i % 3]
+        b.replan()
+        b.launch_distances()
+    got = [b.fetch_distances() for b in batches]
+    for b in batches:
+        b.close()
+    for c in ctxs:
+        c.close()
+    for d, g in zip(datas, got):
+        assert np.array_equal(g, O.edit_distance_batch(*d))
+
+
 @pytest.mark.parametrize("wave", ["", "1"])
 def test_sample_estimate_bounds_the_distances(native, wave, monkeypatch):
     """The sample that picks the window class's mode (malcs_plan.inc: one lane per part of a pair, cuts probed on the

@@ -1,7 +1,8 @@
 """Dev tool: the window kernel's per-wave time stamps (MALCS_DIAG_STAMPS) right behind a plan against a replay over
 the rows of a plan that is already there:  python tools/diag_in_step.py [pairs]"""
 import os, sys
-sys.path.insert(0, "."); sys.path.insert(0, "tests")
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
 import numpy as np
 import gen
 from algebra_amd import _native as N

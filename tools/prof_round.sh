@@ -7,7 +7,7 @@ cd /tmp && export TMPDIR=/tmp
 R=/root/repo
 P=$R/gpurun_out/raw_prof
 rm -rf $P $R/gpurun_out/prof_$TAG; mkdir -p $P $R/gpurun_out/prof_$TAG
-B="python3 $R/bench.py --no-cpu-baseline --no-extra"
+B="python3 $R/bench.py --no-cpu-baseline --no-extra --in-flight 1"   # one stream: kernels of batches in flight side by side stretch each other, and the counters serialise them anyway
 timeout -k 10 300 rocprofv3 --kernel-trace --stats -d $P/stats -o stats -- $B --steps 200 --warmup 20 > $P/stats.log 2>&1
 timeout -s KILL 200 rocprofv3 --pmc FETCH_SIZE -d $P/fetch -o fetch -- $B --steps 20 --warmup 2 > $P/fetch.log 2>&1
 timeout -s KILL 200 rocprofv3 --pmc WRITE_SIZE -d $P/write -o write -- $B --steps 20 --warmup 2 > $P/write.log 2>&1

@@ -1,7 +1,8 @@
 """Dev tool: plan + launch per batch as the bench's headline times it (C2, 100 000 pairs), a few repeats:
     python tools/time_step.py [steps]"""
 import os, sys, time
-sys.path.insert(0, "."); sys.path.insert(0, "tests")
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
 import numpy as np, gen
 from algebra_amd import _native as N
 steps = int(sys.argv[1]) if len(sys.argv) > 1 else 2000
