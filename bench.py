@@ -590,6 +590,19 @@ def main():
                 if traffic is not None:
                     traffic_source = f"profiles/{tag}_pmc.json"
                     break
+        # What a stream of batches in flight asks of memory: the bytes all five launches of a step move (same committed
+        # counter passes, a launch each) against the time a batch takes.
+        step_bytes = None
+        if traffic_source is not None:
+            with open(os.path.join(ROOT, traffic_source)) as f:
+                per_kernel = {k: v.get("hbm_bytes_per_launch") for k, v in json.load(f)["kernels"].items()
+                              if k.startswith(("k_plan_", "k_diag_layout", "k_llcs_diag", "k_llcs_bitpar_list"))}
+            if per_kernel and all(v is not None for v in per_kernel.values()):
+                step_bytes = {"per_kernel": per_kernel, "per_batch": int(sum(per_kernel.values())),
+                              "GB_per_s": round(sum(per_kernel.values()) * args.steps / (elapsed / 1.0) / 1e9, 1),
+                              "frac_of_8000": round(sum(per_kernel.values()) * args.steps / elapsed / 8e12, 4),
+                              "what": "HBM bytes of the plan's three launches + the two distance kernels of one batch (" + traffic_source +
+                                      ") over this run's time per batch on rank 0: what a stream of batches in flight asks of the memory system"}
         replay_s = step_ms * 1e-3
         out = {
             "metric": "GCUPS (batched LCS edit distance, 1 kb windows)",
@@ -612,7 +625,7 @@ def main():
                          "unit": "T int32 lane-op/s", "frac": round(achieved * 1e12 / PEAK_LANE_OPS, 4),
                          "traffic": traffic, "traffic_source": traffic_source, "kernel": kernel_name, "kernel_ms": round(kernel_ms, 4),
                          "kernel_timing": kernel_timing,
-                         "in_step": in_step,
+                         "in_step": in_step, "step_traffic": step_bytes,
                          "frac_back_to_back": round(kernel_cells * OPS_PER_CELL / (back_to_back_ms * 1e-3) / PEAK_LANE_OPS, 4),
                          "launches_timed": launches, "algorithmic": algorithmic,
                          "cells_as_laid_out": padded_cells,
