@@ -440,6 +440,52 @@ __device__ __forceinline__ void diag_halves_lds(uint32_t (&V)[3], uint32_t (&P)[
     pre = got;
 }
 
+// ---- three limbs, match masks from LDS ------------------------------------------------------------------------
+// DIAG_LDS3_STREAM (tools/gen_diag_lds.py): `blocks` plain blocks of a three-limb piece whose text rows hold 2-bit
+// symbols (PIECE_CODES), 10.7 VALU instructions per column where the plane-folding statements above have 14.5.  On
+// entry V[0 ... 1] / P[0 ... 1] are the limbs the window starts with and nxt the rows of its first block (at
+// rows_b + lane); on return they are the limbs it ends with and the rows of the block behind the last one done.
+// `ones` collects the one bits of the limbs that leave (one per block).  The table is the two-limb stream's (16 rows
+// of 64 dwords at LDS address 0): limb j in slot j % 4.
+__device__ __forceinline__ void diag_thirds_lds(uint32_t (&V)[3], uint32_t (&P)[3][2], uint32_t &ones, const uint32_t *rows_b,
+                                                unsigned lane, uint32_t (&nxt)[4], int blocks, uint32_t *tab)
+{
+    auto masks = [](uint32_t p0, uint32_t p1, uint32_t (&mk)[4]) {
+        mk[0] = ~(p0 | p1); mk[1] = p0 & ~p1; mk[2] = ~p0 & p1; mk[3] = p0 & p1;
+    };
+    uint32_t m0[4], m1[4], m2[4];
+    masks(P[0][0], P[0][1], m0);
+    masks(P[1][0], P[1][1], m1);
+    masks(nxt[0], nxt[1], m2);                                             // the rows of a block start with the planes of the limb that enters there
+#pragma unroll
+    for (int k = 0; k < 4; k++) {
+        tab[(0 + k) * 64 + lane] = m0[k];
+        tab[(4 + k) * 64 + lane] = m1[k];
+        tab[(8 + k) * 64 + lane] = m2[k];
+    }
+    if ((uint32_t)reinterpret_cast<uintptr_t>(tab) != 0u) __builtin_trap();   // (the symbol goes into byte 1 of the address)
+    register uint32_t V0 asm("v20") = V[0], V1 asm("v21") = V[1], V2 asm("v24") = ~0u;
+    register uint32_t a0 asm("v57") = P[1][0], a1 asm("v58") = P[1][1], b0 asm("v59") = nxt[0], b1 asm("v60") = nxt[1];
+    register uint32_t p0 asm("v28") = 0u, p1 asm("v29") = 0u;
+    register uint32_t t00 asm("v32") = nxt[2], t01 asm("v36") = nxt[3], t10 asm("v33") = 0u, t11 asm("v37") = 0u;
+    register uint32_t base asm("v30") = lane * 4u;
+    uint32_t voff = lane * 4u, bank = ones;
+    uint32_t cnt = (uint32_t)__builtin_amdgcn_readfirstlane(blocks);
+    asm volatile(DIAG_LDS3_STREAM
+                 : "+v"(V0), "+v"(V1), "+v"(V2), "+v"(a0), "+v"(a1), "+v"(b0), "+v"(b1), "+v"(p0), "+v"(p1),
+                   "+v"(t00), "+v"(t01), "+v"(t10), "+v"(t11), [bank] "+&v"(bank), [voff] "+&v"(voff), [cnt] "+&s"(cnt), "+v"(base)
+                 : [sbase] "s"(rows_b)
+                 : "v22", "v23", "v26", "v27", "v55", "v56", "v31", "v35", "v38", "v39", "v53", "v54", "v40", "v41", "v42", "v43",
+                   "v64", "v65", "v66", "v67", "v68", "v69", "v70", "v71", "v72", "v73", "v74", "v75", "v76", "v77", "v78", "v79",
+                   "v80", "v81", "v82", "v83", "v84", "v85", "v86", "v87", "v88", "v89", "v90", "v91", "v92", "v93", "v94", "v95",
+                   "s40", "s41", "s42", "s44", "s45", "s46", "s47", "s48", "s49", "s50", "s51", "scc", "memory");
+    V[0] = V0; V[1] = V1;
+    P[0][0] = a0; P[0][1] = a1; P[1][0] = b0; P[1][1] = b1;
+    nxt[0] = p0; nxt[1] = p1;
+    nxt[2] = (blocks & 1) ? t10 : t00; nxt[3] = (blocks & 1) ? t11 : t01;   // block i leaves the next one's text in the registers of parity i + 1
+    ones = bank;
+}
+
 // The same for the other classes: loads the compiler does not see, and a wait statement that every
 // destination passes through before its first use (the loads are unconditional: the buffer is padded).
 template <int J>
@@ -489,7 +535,7 @@ k_llcs_diag(const uint32_t *__restrict__ rows, const uint32_t *__restrict__ piec
     constexpr int T = 32 * NLW - 32;
     // dev (MALCS_DIAG_STAMPS): the 100 MHz wall clock at four points of every wave + where it runs
     auto stamp = [&](int k) {
-        if (stamps > reinterpret_cast<unsigned long long *>(1) && threadIdx.x == 0) {
+        if (stamps > reinterpret_cast<unsigned long long *>(3) && threadIdx.x == 0) {     // (1, 2: switches, see malcs_diag_launch)
             unsigned long long t = wall_clock64();
             if (k == 0) { uint32_t hw, xcc; asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hw)); asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc)); stamps[(blockIdx.x - pad) * 6ull + 4] = hw; stamps[(blockIdx.x - pad) * 6ull + 5] = (xcc & 15u) | ((unsigned long long)piece_info[blockIdx.x - pad] << 8); }
             stamps[(blockIdx.x - pad) * 6ull + k] = t;
@@ -573,12 +619,12 @@ k_llcs_diag(const uint32_t *__restrict__ rows, const uint32_t *__restrict__ piec
 
     int32_t d = 0;
     bool have_d = false, skip = false;                 // skip: the other part of the tile reports this lane's pair
+    __shared__ __attribute__((aligned(4096))) uint32_t lds_masks[NLW == 3 && NP == 2 && FUSED ? 16 * 64 : 1];   // the match masks of the LDS streams
     if constexpr (NLW == 3 && NP == 2 && FUSED) {
         if (halves) {                                  // every block of every lane is plain (the plan saw to that)
             uint32_t ones = 0;
             unsigned long long pre = 0ull;             // the other part's join word, if it was there shortly before the end
             if (info & PIECE_CODES) {
-                __shared__ __attribute__((aligned(4096))) uint32_t lds_masks[16 * 64];
                 diag_halves_lds(V, P, ones, rows_u + (META_ROWS + (NLW - 1) * NP) * 64, lane, nxt, iters, lds_masks,
                                 join_slots, (info & PIECE_JOINED) != 0u, pre);
             } else {
@@ -654,9 +700,37 @@ k_llcs_diag(const uint32_t *__restrict__ rows, const uint32_t *__restrict__ piec
         }
     }
     if (!have_d && !(halves && (info & PIECE_JOINED))) {
+        // text rows that hold 2-bit symbols (PIECE_CODES: written for the LDS streams) as the two planes the other paths read
+        auto planes_of = [](uint32_t c0, uint32_t c1, uint32_t (&w)[NP]) {
+            auto even = [](uint32_t x) -> uint32_t {
+                x &= 0x55555555u; x = (x | (x >> 1)) & 0x33333333u; x = (x | (x >> 2)) & 0x0f0f0f0fu;
+                x = (x | (x >> 4)) & 0x00ff00ffu; x = (x | (x >> 8)) & 0xffffu;
+                return x;
+            };
+            w[0] = even(c0) | (even(c1) << 16);
+            if constexpr (NP >= 2) w[1] = even(c0 >> 1) | (even(c1 >> 1) << 16);
+        };
+        const bool codes = NP == 2 && !halves && (info & PIECE_CODES);
         for (int it = halves ? iters : 0; it < iters;) {
             if constexpr (NLW == 3 && NP == 2 && FUSED) {
-                auto plain3 = [&](int i) { return i + 3 <= iters && __builtin_amdgcn_ballot_w64(i + 3 > plain_hi) == 0; };
+                if (codes && it == 0) {
+                    // the blocks every lane of the wave can run without masks, through the LDS stream (all of them in a
+                    // piece the plan made: it grows the sequences to whole blocks and to the tile's longest)
+                    int lo = min(plain_hi, iters);
+#pragma unroll
+                    for (int o = 32; o > 0; o >>= 1) lo = min(lo, __shfl_xor(lo, o, 64));
+                    const int n_lds = __builtin_amdgcn_readfirstlane(lo);
+                    if (n_lds >= 1 && stamps != reinterpret_cast<unsigned long long *>(2)) {
+                        uint32_t ones = 0;
+                        diag_thirds_lds(V, P, ones, rows_u + (META_ROWS + (NLW - 1) * NP) * 64, lane, nxt, n_lds, lds_masks);
+                        banked += 32u * (uint32_t)n_lds - ones;
+                        above = min(kmax, 32 * n_lds);         // the rows above the matrix in the limbs that left, banked as zeros (V = 0 there)
+                        p += (size_t)n_lds * 2 * NP * 64;
+                        it = n_lds;
+                        continue;
+                    }
+                }
+                auto plain3 = [&](int i) { return !codes && i + 3 <= iters && __builtin_amdgcn_ballot_w64(i + 3 > plain_hi) == 0; };
                 if (plain3(it)) {
                     if (it == 0) above = kmax;                 // kmax <= 64: rows [-kmax, 0) lie in the first three leaving limbs
                     diag_triples_dna3(V, P, banked, p, nxt, it, plain3);
@@ -666,6 +740,7 @@ k_llcs_diag(const uint32_t *__restrict__ rows, const uint32_t *__restrict__ piec
             uint32_t w[NP];
 #pragma unroll
             for (int q = 0; q < NP; q++) { P[NLW - 1][q] = nxt[q]; w[q] = nxt[NP + q]; }
+            if constexpr (NP == 2) { if (codes) planes_of(nxt[2], nxt[3], w); }
             V[NLW - 1] = ~0u;
             p += 2 * NP * 64;                          // rows of the next block (the buffer ends with one block of padding)
             const int hi = (int)n - 32 * it;           // one past the last valid step of the block: steps beyond must not change V
@@ -986,7 +1061,7 @@ int malcs_diag_plan(malcs_batch *b)
     if (!d.cut_possible) A.cut_mode = 0;
     A.cut_possible = d.cut_possible;
     // MALCS_DIAG_LDS=0: two-limb pieces fold the match masks from the planes (diag_halves_dna) instead of reading them from LDS
-    A.lds_codes = NP == 2 && !(getenv("MALCS_DIAG_LDS") && atoi(getenv("MALCS_DIAG_LDS")) == 0);
+    A.lds_codes = NP == 2 && d.nlw == 3 && !(getenv("MALCS_DIAG_LDS") && atoi(getenv("MALCS_DIAG_LDS")) == 0);
     A.balance = !(getenv("MALCS_DIAG_BALANCE") && atoi(getenv("MALCS_DIAG_BALANCE")) == 0);     // 0: middle cuts only
     A.trim = !(getenv("MALCS_DIAG_TRIM") && atoi(getenv("MALCS_DIAG_TRIM")) == 0);              // 0 keeps the common ends inside the window
     int logL = 0;
@@ -1097,6 +1172,9 @@ int malcs_diag_launch(malcs_batch *b, bool advance, hipEvent_t start, hipEvent_t
     // (the buffer is made by the first launch that asks and kept: a launch right behind a plan must not wait for an allocation)
     static unsigned long long *stamp_buf = nullptr;
     static size_t stamp_cap = 0;
+    // MALCS_DIAG_LDS3=0: three-limb pieces do not use their LDS stream (their text rows still hold 2-bit symbols: the
+    // plane-folding paths turn them back into planes) -- for the comparison and for the test of that path
+    if (getenv("MALCS_DIAG_LDS3") && atoi(getenv("MALCS_DIAG_LDS3")) == 0) stamps = reinterpret_cast<unsigned long long *>(2);
     if (stamp_path && *stamp_path) {
         if (stamp_cap < (size_t)d.n_launch * 48) {
             MALCS_HIP(hipStreamSynchronize(st));
@@ -1124,7 +1202,7 @@ int malcs_diag_launch(malcs_batch *b, bool advance, hipEvent_t start, hipEvent_t
         hipLaunchKernelGGL(fn, dim3(d.n_launch + pad), dim3(64), 0, st, d.d_rows, d.d_piece_off, d.d_piece_info, d.d_piece_join, b->d_dist,
                            d.d_retry_list, d.d_retry_first, d.d_retry_cap, cur, next, advance ? ncls : 0u, d.d_join_buf, stamps, pad);
     MALCS_HIP(hipGetLastError());
-    if (stamps > reinterpret_cast<unsigned long long *>(1)) {
+    if (stamps > reinterpret_cast<unsigned long long *>(3)) {
         std::vector<unsigned long long> host((size_t)d.n_launch * 6);
         MALCS_HIP(hipStreamSynchronize(st));
         MALCS_HIP(hipMemcpy(host.data(), stamps, host.size() * 8, hipMemcpyDeviceToHost));

@@ -288,6 +288,38 @@ def test_edit_distance_two_limb_mode(native, half, monkeypatch):
     assert np.array_equal(got, O.edit_distance_batch(*data))
 
 
+@pytest.mark.parametrize("lds3", ["", "0"])
+def test_three_limb_pieces_lds_stream_and_plane_paths(native, lds3, monkeypatch):
+    """Three-limb pieces of DNA batches run through a generated stream that reads its match masks from LDS
+    (DIAG_LDS3_STREAM; their text rows hold 2-bit symbols).  MALCS_DIAG_LDS3=0 sends the same rows through the
+    plane-folding paths, which turn the symbols back into planes; MALCS_DIAG_LDS=0 (no symbols in the rows at all) is
+    the stream of round 2.  Forced three limbs, cut and uncut tiles, lengths whose pieces are a few blocks and many:
+    all three give the oracle's distances."""
+    from oracle import oracle as O
+    monkeypatch.setenv("MALCS_DIAG_HALF", "0")
+    if lds3:
+        monkeypatch.setenv("MALCS_DIAG_LDS3", lds3)
+    for pairs, length, p, cut, seed in [(6000, 1000, 0.02, "", 41), (5000, 330, 0.03, "1", 42), (4200, 2500, 0.01, "1", 43), (9000, 400, 0.05, "0", 44)]:
+        if cut:
+            monkeypatch.setenv("MALCS_DIAG_CUT", cut)
+        else:
+            monkeypatch.delenv("MALCS_DIAG_CUT", raising=False)
+        data = gen.c2_batch(pairs, seed=seed, length=length, p=p)
+        ref = O.edit_distance_batch(*data)
+        batch = native.Batch(native.default_context(), *data, n_symbols=4)
+        info = batch.plan_info()
+        got = batch.distances()
+        batch.close()
+        assert info["window_tiles"] > 0 and info["two_limb_tiles"] == 0
+        assert np.array_equal(got, ref), (length, p, cut)
+    monkeypatch.setenv("MALCS_DIAG_LDS", "0")
+    data = gen.c2_batch(5000, seed=45, length=800, p=0.02)
+    batch = native.Batch(native.default_context(), *data, n_symbols=4)
+    got = batch.distances()
+    batch.close()
+    assert np.array_equal(got, O.edit_distance_batch(*data))
+
+
 def test_batches_in_flight_on_streams_of_their_own(native):
     """bench.py keeps three batches in flight, each on a context (= stream) of its own, so that one batch's plan runs
     beside another's distance kernels.  Plans and launches queued in turn, many times over, without a wait in between:

@@ -274,6 +274,144 @@ def generate():
     return st.lines
 
 
+# ---- three limbs (T = 64): the same idea without half steps -------------------------------------------------------------
+# Block i runs on the limbs w[i], w[i + 1], w[i + 2] and moves down one limb at its end.  LDS: four slots of four symbol
+# rows, limb j in slot j % 4 -- the limb that enters block i + 1 (w[i + 3]: its planes were asked for at the start of
+# block i) is written while block i still reads the other three, so the loop body is four blocks (the slots are offsets
+# of the instructions).  A column: v_and_b32_sdwa (address) + ds_read2st64_b32 (limbs 0, 1) + ds_read_b32 (limb 2) for the
+# column LOOKAHEAD3 ahead, then per limb v_and_b32, v_add(c)_co_u32, v_bitop3_b32: 10 VALU instructions where the
+# plane-folding stream (TG_STEP in malcs_diag.hip) has 14.  Limb k lags k columns behind limb 0, so the carries cross
+# between steps; a block is 34 steps.  The planes of the two limbs that stay are kept (PA, PB) for whatever follows
+# the stream.  The loop can be left after any block.
+LOOKAHEAD3 = int(os.environ.get("GEN_LOOKAHEAD3", "5"))
+RING3 = 8
+V3 = ["v20", "v21", "v24"]
+U3 = ["v22", "v26", "v55"]
+S3 = ["v23", "v27", "v56"]
+PA, PB = ("v57", "v58"), ("v59", "v60")
+NEW3 = ["v40", "v41", "v42", "v43"]
+C01 = ["s[40:41]", "s[44:45]"]       # limb 0 -> limb 1
+C12 = ["s[46:47]", "s[50:51]"]       # limb 1 -> limb 2
+WAITCOL3 = 32 - LOOKAHEAD3 - 2       # from this step on the next block's rows are there (its text is needed LOOKAHEAD3 columns before its start)
+
+
+def ring3(col):
+    assert 32 % RING3 == 0 and RING3 >= LOOKAHEAD3 + 3
+    k = col % RING3
+    return f"v[{64 + 4 * k}:{65 + 4 * k}]", f"v{64 + 4 * k}", f"v{65 + 4 * k}", f"v{66 + 4 * k}"     # (register pairs start at even registers)
+
+
+def read_column3(st, ph, G, key):
+    """LDS reads of column G (0 ... 31: this block, of phase ph = i % 4; 32 ...: the next block)."""
+    first = ph if G < 32 else ph + 1
+    slots = [(first + k) % 4 for k in range(3)]
+    a = ADDR[st.addr_turn]
+    st.addr_turn ^= 1
+    pair, _, _, third = ring3(G)
+    text, k = text_of(ph % 2, G)
+    if k == 0:
+        for j in (1, 2, 3):
+            st.emit(f"v_lshrrev_b32 {SHT[j - 1]}, {2 * j}, {text}")
+    src = text if k % 4 == 0 else SHT[k % 4 - 1]
+    st.emit(f"v_and_b32_sdwa {a}, {src}, {THREE} dst_sel:BYTE_1 dst_unused:UNUSED_PRESERVE src0_sel:BYTE_{k // 4} src1_sel:DWORD")
+    st.ds(f"ds_read2st64_b32 {pair}, {a} offset0:{4 * slots[0]} offset1:{4 * slots[1]}")
+    st.read_at[key] = st.ds_issued            # (a column is waited for as a whole: the drain steps wait for nothing else)
+    st.ds(f"ds_read_b32 {third}, {a} offset:{4 * slots[2] * 256}")
+
+
+def block3(st, ph, row_offset):
+    e = ph % 2
+    if PRIO:
+        set_priority(st, f"3{ph}")
+    nt = TEXT[1 - e]
+    # the rows of the next block: the planes of the limb that enters there and its text (2-bit symbols)
+    st.emit(f"global_load_dword {PL0}, %[voff], %[sbase] offset:{row_offset}{NT}")
+    st.emit(f"global_load_dword {PL1}, %[voff], %[sbase] offset:{row_offset + 256}{NT}")
+    st.emit(f"global_load_dword {nt[0]}, %[voff], %[sbase] offset:{row_offset + 512}{NT}")
+    st.emit(f"global_load_dword {nt[1]}, %[voff], %[sbase] offset:{row_offset + 768}{NT}")
+    for s in range(34):
+        if s == WAITCOL3:
+            st.emit("s_waitcnt vmcnt(0)")
+            st.emit(f"v_and_b32 {NEW3[3]}, {PL0}, {PL1}")
+            st.emit(f"v_bitop3_b32 {NEW3[0]}, {PL0}, {PL1}, {PL1} bitop3:0x03")
+            st.emit(f"v_xor_b32 {NEW3[1]}, {PL0}, {NEW3[3]}")
+            st.emit(f"v_xor_b32 {NEW3[2]}, {PL1}, {NEW3[3]}")
+            slot = 4 * ((ph + 3) % 4)
+            st.ds(f"ds_write2st64_b32 {BASE}, {NEW3[0]}, {NEW3[1]} offset0:{slot} offset1:{slot + 1}")
+            st.ds(f"ds_write2st64_b32 {BASE}, {NEW3[2]}, {NEW3[3]} offset0:{slot + 2} offset1:{slot + 3}")
+        if s < 32 and s + LOOKAHEAD3 < 32 + LOOKAHEAD3:
+            G = s + LOOKAHEAD3
+            read_column3(st, ph, G, ("n", G - 32) if G >= 32 else ("c", G))
+        if s < 32:
+            st.wait_read(("c", s))
+        if s >= 2:
+            st.emit(f"v_and_b32 {U3[2]}, {V3[2]}, {ring3(s - 2)[3]}")
+        if 1 <= s <= 32:
+            st.emit(f"v_and_b32 {U3[1]}, {V3[1]}, {ring3(s - 1)[2]}")
+        if s < 32:
+            st.emit(f"v_and_b32 {U3[0]}, {V3[0]}, {ring3(s)[1]}")
+        if s >= 2:
+            st.emit(f"v_addc_co_u32_e64 {S3[2]}, {CARRY_TOP}, {V3[2]}, {U3[2]}, {C12[(s - 1) % 2]}")
+        if 1 <= s <= 32:
+            st.emit(f"v_addc_co_u32_e64 {S3[1]}, {C12[s % 2]}, {V3[1]}, {U3[1]}, {C01[(s - 1) % 2]}")
+        if s < 32:
+            st.emit(f"v_add_co_u32_e64 {S3[0]}, {C01[s % 2]}, {V3[0]}, {U3[0]}")
+        if s >= 2:
+            st.emit(f"v_bitop3_b32 {V3[2]}, {U3[2]}, {S3[2]}, {V3[2]} bitop3:0xde")
+        if 1 <= s <= 32:
+            st.emit(f"v_bitop3_b32 {V3[1]}, {U3[1]}, {S3[1]}, {V3[1]} bitop3:0xde")
+        if s < 32:
+            st.emit(f"v_bitop3_b32 {V3[0]}, {U3[0]}, {S3[0]}, {V3[0]} bitop3:0xde")
+    # the window moves down one limb: the ones of the limb that leaves are counted, all ones enter on top; the planes
+    # of the limbs that stay follow (the next block's loads overwrite PL)
+    st.emit(f"v_bcnt_u32_b32 %[bank], {V3[0]}, %[bank]")
+    st.emit(f"v_mov_b32 {V3[0]}, {V3[1]}")
+    st.emit(f"v_mov_b32 {V3[1]}, {V3[2]}")
+    st.emit(f"v_mov_b32 {V3[2]}, -1")
+    st.emit(f"v_mov_b32 {PA[0]}, {PB[0]}")
+    st.emit(f"v_mov_b32 {PA[1]}, {PB[1]}")
+    st.emit(f"v_mov_b32 {PB[0]}, {PL0}")
+    st.emit(f"v_mov_b32 {PB[1]}, {PL1}")
+    assert all(k[0] == "n" for k in st.read_at), st.read_at
+    st.read_at = {("c", k[1]): v for k, v in st.read_at.items()}
+
+
+def generate3():
+    st = Stream()
+    st.emit(f"v_mov_b32 {THREE}, 3")
+    st.emit(f"v_mov_b32 {ADDR[0]}, {BASE}")
+    st.emit(f"v_mov_b32 {ADDR[1]}, {BASE}")
+    for g in range(LOOKAHEAD3):
+        read_column3(st, 0, g, ("c", g))
+    entry = {k: st.ds_issued - v for k, v in st.read_at.items()}
+    turn = st.addr_turn
+    st.lines.append(".p2align 3")
+    st.pos = 0
+    st.emit("Ldiag_lds3_loop%=:")
+    for ph in range(4):
+        block3(st, ph, 1024 if ph % 2 == 0 else 2048)
+        if ph % 2 == 1:
+            st.emit("v_add_u32 %[voff], 0x800, %[voff]")
+        st.emit("s_sub_u32 %[cnt], %[cnt], 1")
+        st.emit("s_cmp_eq_u32 %[cnt], 0")
+        st.emit("s_cbranch_scc1 Ldiag_lds3_done%=" if ph < 3 else "s_cbranch_scc0 Ldiag_lds3_loop%=")
+        assert {k: st.ds_issued - v for k, v in st.read_at.items()} == entry, (ph, st.read_at)
+    assert st.addr_turn == turn
+    st.emit("Ldiag_lds3_done%=:")
+    if PRIO:
+        st.emit("s_setprio 0")
+    st.emit("s_waitcnt vmcnt(0) lgkmcnt(0)")
+    return st.lines
+
+
+def write_macro(f, name, lines):
+    f.write(f"#define {name} \\\n")
+    for i, line in enumerate(lines):
+        end = "\\n\\t" if i + 1 < len(lines) else ""
+        cont = " \\" if i + 1 < len(lines) else ""
+        f.write(f'    "{line}{end}"{cont}\n')
+
+
 def main():
     lines = generate()
     out = os.environ.get("GEN_OUT") or os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "algebra_amd", "csrc", "malcs_diag_lds.inc")
@@ -281,11 +419,13 @@ def main():
         f.write("// Generated by tools/gen_diag_lds.py -- do not edit.  The two-limb window stream with match masks from LDS\n")
         f.write(f"// (lookahead {LOOKAHEAD} columns, ring of {RING} register pairs); registers and operands: see diag_halves_lds.\n")
         f.write(f'#define DIAG_LDS_V0 "{V0}"\n#define DIAG_LDS_V1 "{V1}"\n#define DIAG_LDS_JOINPRE {JOINPRE}\n')
-        f.write("#define DIAG_LDS_STREAM \\\n")
-        for i, line in enumerate(lines):
-            end = "\\n\\t" if i + 1 < len(lines) else ""
-            cont = " \\" if i + 1 < len(lines) else ""
-            f.write(f'    "{line}{end}"{cont}\n')
+        write_macro(f, "DIAG_LDS_STREAM", lines)
+        lines3 = generate3()
+        f.write(f"// The three-limb window stream with match masks from LDS (lookahead {LOOKAHEAD3} columns, ring of {RING3} register triples);\n")
+        f.write("// registers and operands: see diag_thirds_lds.\n")
+        write_macro(f, "DIAG_LDS3_STREAM", lines3)
+        n3 = sum(1 for l in lines3 if l.startswith("v_"))
+        print(f"three limbs: {len(lines3)} lines, {n3} VALU instructions for four blocks + preamble -> {n3 / 128:.2f} per column")
     n_valu = sum(1 for l in lines if l.startswith("v_"))
     print(f"{len(lines)} lines, {n_valu} VALU instructions for two blocks + preamble -> {n_valu / 64:.2f} per column, "
           f"{sum(1 for l in lines if l == 's_nop 0')} s_nop")
