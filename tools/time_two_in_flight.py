@@ -6,11 +6,12 @@ sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
 import numpy as np, gen
 from algebra_amd import _native as N
 steps = int(sys.argv[1]) if len(sys.argv) > 1 else 2000
-ctxs = [N.Context(0) for _ in range(3)]
+NF = int(os.environ.get('NF', '3'))
+ctxs = [N.Context(0) for _ in range(NF)]
 bs = [N.Batch(c, *gen.c2_batch(100000, seed=2 + i), 4) for i, c in enumerate(ctxs)]
 for b in bs:
     b.distances()
-for k in (1, 2, 3):
+for k in range(1, NF + 1):
     out = []
     for rep in range(4):
         for i in range(60):
