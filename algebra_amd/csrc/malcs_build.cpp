@@ -797,7 +797,7 @@ static int graph_batch(malcs_batch *b, const int64_t *shift, const int64_t *max_
     }
 
     size_t free_b = 0, total_b = 0;
-    MALCS_HIP(hipMemGetInfo(&free_b, &total_b));
+    if (!classes.empty()) MALCS_HIP(hipMemGetInfo(&free_b, &total_b));     // (only the bit-vector classes size their chunks by it; the call is 0.2 ms)
     const uint64_t budget_dwords = std::min<uint64_t>(free_b / 2, 64ull << 30) / 4;
 
     stages.lap("launch classes");
