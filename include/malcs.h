@@ -53,7 +53,11 @@ int malcs_version(void);
 const char *malcs_last_error(void);
 int malcs_device_count(int *count);
 
-/* Bind a context (stream, scratch) to HIP device `device`. */
+/* Bind a context (stream, scratch) to HIP device `device`.  Contexts share nothing but the device: a caller with a
+ * stream of batches makes two or three on the same device and puts consecutive batches on them in turn, so that one
+ * batch's plan (launches that mostly wait for memory) runs beside another's distance kernels (bound by the VALU);
+ * more than the card's four hardware queues gains nothing.  A context is not thread-safe; different contexts may be
+ * used from different threads. */
 int malcs_ctx_create(int device, malcs_ctx **ctx);
 int malcs_ctx_destroy(malcs_ctx *ctx);
 int malcs_ctx_sync(malcs_ctx *ctx);
