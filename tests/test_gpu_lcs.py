@@ -320,6 +320,26 @@ def test_three_limb_pieces_lds_stream_and_plane_paths(native, lds3, monkeypatch)
     assert np.array_equal(got, O.edit_distance_batch(*data))
 
 
+@pytest.mark.parametrize("pad", ["0", "1", "1000"])
+def test_window_kernel_with_other_numbers_of_leading_workgroups(native, pad, monkeypatch):
+    """The window kernel's launch starts with workgroups that return at once (one per CU: they take the hardware's
+    first turn so that the pieces land where the deal expects them, malcs_diag_launch).  Their number moves the pieces'
+    workgroup indices, nothing else: none, one, and a number that is no multiple of anything give the same distances,
+    first launch and replays, cut tiles included."""
+    from oracle import oracle as O
+    monkeypatch.setenv("MALCS_DIAG_PAD", pad)
+    for pairs, length, p, seed in [(20000, 1000, 0.01, 51), (5000, 600, 0.03, 52)]:
+        data = gen.c2_batch(pairs, seed=seed, length=length, p=p)
+        batch = native.Batch(native.default_context(), *data, n_symbols=4)
+        got = batch.distances()
+        batch.replan()
+        batch.launch_distances()
+        again = batch.fetch_distances()
+        batch.close()
+        ref = O.edit_distance_batch(*data)
+        assert np.array_equal(got, ref) and np.array_equal(again, ref), (pad, length)
+
+
 def test_batches_in_flight_on_streams_of_their_own(native):
     """bench.py keeps three batches in flight, each on a context (= stream) of its own, so that one batch's plan runs
     beside another's distance kernels.  Plans and launches queued in turn, many times over, without a wait in between:
