@@ -150,6 +150,29 @@ def test_edit_distance_c2_full_size(native):
     assert 15 < d.mean() < 25
 
 
+def test_edit_distance_c2_full_size_every_kernel_agrees(native, monkeypatch):
+    """BASELINE config 2 at full size through every kernel that can take it: the window class as the plan picks it (two
+    limbs), forced to three limbs (LDS stream, and the plane-folding paths), and the full-matrix kernel alone -- four
+    instruction streams, one answer, and that answer is the oracle's on all 100 000 pairs."""
+    from oracle import oracle as O
+    data = gen.c2_batch(100000)
+    ref = O.edit_distance_batch(*data)
+    for env in ({}, {"MALCS_DIAG_HALF": "0"}, {"MALCS_DIAG_HALF": "0", "MALCS_DIAG_LDS3": "0"}, {"MALCS_DIAG_NLW": "0"}):
+        for k, v in env.items():
+            monkeypatch.setenv(k, v)
+        batch = native.Batch(native.default_context(), *data, n_symbols=4)
+        info = batch.plan_info()
+        got = batch.distances()
+        batch.close()
+        for k in env:
+            monkeypatch.delenv(k)
+        assert np.array_equal(got, ref), env
+        if "MALCS_DIAG_NLW" in env:
+            assert info["window_tiles"] == 0
+        else:
+            assert info["window_tiles"] == 1563 and (info["two_limb_tiles"] == 0) == ("MALCS_DIAG_HALF" in env)
+
+
 def _window_class_batch(rs, n_pairs, nsym):
     """Pairs long enough for the window class, divergence from identical to unrelated, length gaps up to 300."""
     seqs = []
