@@ -442,6 +442,12 @@ class VariantGraphBatch(MutableSequence):
         except UnicodeEncodeError:
             return None
         starts, ends, seqs = [], [], []
+        if all(len(variants) == 1 for variants in alleles):      # the usual case, without a Python statement per field and allele
+            singles = [variants[0] for variants in alleles]
+            starts = [v.start for v in singles]
+            ends = [v.end for v in singles]
+            seqs = [v.sequence for v in singles]
+            alleles = ()
         for variants in alleles:
             if not variants:                                    # no variant: the allele changes nothing
                 starts.append(0); ends.append(0); seqs.append("")
