@@ -465,14 +465,15 @@ __device__ __forceinline__ void diag_thirds_lds(uint32_t (&V)[3], uint32_t (&P)[
     }
     if ((uint32_t)reinterpret_cast<uintptr_t>(tab) != 0u) __builtin_trap();   // (the symbol goes into byte 1 of the address)
     register uint32_t V0 asm("v20") = V[0], V1 asm("v21") = V[1], V2 asm("v24") = ~0u;
-    register uint32_t a0 asm("v57") = P[1][0], a1 asm("v58") = P[1][1], b0 asm("v59") = nxt[0], b1 asm("v60") = nxt[1];
+    register uint32_t a0 asm("v57") = P[0][0], a1 asm("v58") = P[0][1], b0 asm("v59") = P[1][0], b1 asm("v60") = P[1][1];
+    register uint32_t c0 asm("v61") = nxt[0], c1 asm("v62") = nxt[1];          // the planes of the window's three limbs follow it
     register uint32_t p0 asm("v28") = 0u, p1 asm("v29") = 0u;
     register uint32_t t00 asm("v32") = nxt[2], t01 asm("v36") = nxt[3], t10 asm("v33") = 0u, t11 asm("v37") = 0u;
     register uint32_t base asm("v30") = lane * 4u;
     uint32_t voff = lane * 4u, bank = ones;
     uint32_t cnt = (uint32_t)__builtin_amdgcn_readfirstlane(blocks);
     asm volatile(DIAG_LDS3_STREAM
-                 : "+v"(V0), "+v"(V1), "+v"(V2), "+v"(a0), "+v"(a1), "+v"(b0), "+v"(b1), "+v"(p0), "+v"(p1),
+                 : "+v"(V0), "+v"(V1), "+v"(V2), "+v"(a0), "+v"(a1), "+v"(b0), "+v"(b1), "+v"(c0), "+v"(c1), "+v"(p0), "+v"(p1),
                    "+v"(t00), "+v"(t01), "+v"(t10), "+v"(t11), [bank] "+&v"(bank), [voff] "+&v"(voff), [cnt] "+&s"(cnt), "+v"(base)
                  : [sbase] "s"(rows_b)
                  : "v22", "v23", "v26", "v27", "v55", "v56", "v31", "v35", "v38", "v39", "v53", "v54", "v40", "v41", "v42", "v43",
@@ -719,7 +720,8 @@ k_llcs_diag(const uint32_t *__restrict__ rows, const uint32_t *__restrict__ piec
                     int lo = min(plain_hi, iters);
 #pragma unroll
                     for (int o = 32; o > 0; o >>= 1) lo = min(lo, __shfl_xor(lo, o, 64));
-                    const int n_lds = __builtin_amdgcn_readfirstlane(lo);
+                    int n_lds = __builtin_amdgcn_readfirstlane(lo);
+                    if (stamps == reinterpret_cast<unsigned long long *>(3)) n_lds = max(1, n_lds / 2);    // (test switch: the rest through the plane paths)
                     if (n_lds >= 1 && stamps != reinterpret_cast<unsigned long long *>(2)) {
                         uint32_t ones = 0;
                         diag_thirds_lds(V, P, ones, rows_u + (META_ROWS + (NLW - 1) * NP) * 64, lane, nxt, n_lds, lds_masks);
@@ -1173,8 +1175,12 @@ int malcs_diag_launch(malcs_batch *b, bool advance, hipEvent_t start, hipEvent_t
     static unsigned long long *stamp_buf = nullptr;
     static size_t stamp_cap = 0;
     // MALCS_DIAG_LDS3=0: three-limb pieces do not use their LDS stream (their text rows still hold 2-bit symbols: the
-    // plane-folding paths turn them back into planes) -- for the comparison and for the test of that path
-    if (getenv("MALCS_DIAG_LDS3") && atoi(getenv("MALCS_DIAG_LDS3")) == 0) stamps = reinterpret_cast<unsigned long long *>(2);
+    // plane-folding paths turn them back into planes) -- for the comparison and for the test of that path; 2: the stream
+    // stops half way through every piece (the hand-over between the two, which no piece of a plan needs)
+    if (const char *e = getenv("MALCS_DIAG_LDS3")) {
+        if (atoi(e) == 0) stamps = reinterpret_cast<unsigned long long *>(2);
+        else if (atoi(e) == 2) stamps = reinterpret_cast<unsigned long long *>(3);       // half of a piece's blocks through the stream, the rest through the plane paths
+    }
     if (stamp_path && *stamp_path) {
         if (stamp_cap < (size_t)d.n_launch * 48) {
             MALCS_HIP(hipStreamSynchronize(st));

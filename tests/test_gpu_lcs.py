@@ -311,11 +311,12 @@ def test_edit_distance_two_limb_mode(native, half, monkeypatch):
     assert np.array_equal(got, O.edit_distance_batch(*data))
 
 
-@pytest.mark.parametrize("lds3", ["", "0"])
+@pytest.mark.parametrize("lds3", ["", "0", "2"])
 def test_three_limb_pieces_lds_stream_and_plane_paths(native, lds3, monkeypatch):
     """Three-limb pieces of DNA batches run through a generated stream that reads its match masks from LDS
     (DIAG_LDS3_STREAM; their text rows hold 2-bit symbols).  MALCS_DIAG_LDS3=0 sends the same rows through the
-    plane-folding paths, which turn the symbols back into planes; MALCS_DIAG_LDS=0 (no symbols in the rows at all) is
+    plane-folding paths, which turn the symbols back into planes, =2 leaves the stream half way through every piece and
+    hands the rest to them; MALCS_DIAG_LDS=0 (no symbols in the rows at all) is
     the stream of round 2.  Forced three limbs, cut and uncut tiles, lengths whose pieces are a few blocks and many:
     all three give the oracle's distances."""
     from oracle import oracle as O

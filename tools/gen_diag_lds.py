@@ -281,14 +281,14 @@ def generate():
 # of the instructions).  A column: v_and_b32_sdwa (address) + ds_read2st64_b32 (limbs 0, 1) + ds_read_b32 (limb 2) for the
 # column LOOKAHEAD3 ahead, then per limb v_and_b32, v_add(c)_co_u32, v_bitop3_b32: 10 VALU instructions where the
 # plane-folding stream (TG_STEP in malcs_diag.hip) has 14.  Limb k lags k columns behind limb 0, so the carries cross
-# between steps; a block is 34 steps.  The planes of the two limbs that stay are kept (PA, PB) for whatever follows
+# between steps; a block is 34 steps.  The planes of the window's limbs follow it (PA, PB, PC) for whatever follows
 # the stream.  The loop can be left after any block.
 LOOKAHEAD3 = int(os.environ.get("GEN_LOOKAHEAD3", "5"))
 RING3 = 8
 V3 = ["v20", "v21", "v24"]
 U3 = ["v22", "v26", "v55"]
 S3 = ["v23", "v27", "v56"]
-PA, PB = ("v57", "v58"), ("v59", "v60")
+PA, PB, PC = ("v57", "v58"), ("v59", "v60"), ("v61", "v62")      # planes of the limbs w[i], w[i + 1], w[i + 2] of block i
 NEW3 = ["v40", "v41", "v42", "v43"]
 C01 = ["s[40:41]", "s[44:45]"]       # limb 0 -> limb 1
 C12 = ["s[46:47]", "s[50:51]"]       # limb 1 -> limb 2
@@ -370,8 +370,10 @@ def block3(st, ph, row_offset):
     st.emit(f"v_mov_b32 {V3[2]}, -1")
     st.emit(f"v_mov_b32 {PA[0]}, {PB[0]}")
     st.emit(f"v_mov_b32 {PA[1]}, {PB[1]}")
-    st.emit(f"v_mov_b32 {PB[0]}, {PL0}")
-    st.emit(f"v_mov_b32 {PB[1]}, {PL1}")
+    st.emit(f"v_mov_b32 {PB[0]}, {PC[0]}")
+    st.emit(f"v_mov_b32 {PB[1]}, {PC[1]}")
+    st.emit(f"v_mov_b32 {PC[0]}, {PL0}")
+    st.emit(f"v_mov_b32 {PC[1]}, {PL1}")
     assert all(k[0] == "n" for k in st.read_at), st.read_at
     st.read_at = {("c", k[1]): v for k, v in st.read_at.items()}
 
