@@ -162,12 +162,28 @@ __device__ __forceinline__ uint32_t bits_at(const uint32_t *__restrict__ S, uint
 
 // mismatch bits of the 32 cells (row + i, col + i); REV: of the problem on the reversed sequences, where cell
 // (r, c) is the original cell (m - 1 - r, n - 1 - c).  Cells outside the matrix come out arbitrary.
+// DNA: both planes of a block in one 8-byte load (half the loads, clamps and selects of two calls of bits_at)
+__device__ __forceinline__ uint2 bits_at_dna(const uint32_t *__restrict__ S, uint32_t nblk, int32_t start)
+{
+    const int32_t j = start >> 5, last = (int32_t)nblk - 1;
+    const uint32_t s = (uint32_t)start & 31u;
+    const uint2 l0 = *reinterpret_cast<const uint2 *>(S + (uint32_t)min(max(j, 0), last) * 2u);
+    const uint2 l1 = *reinterpret_cast<const uint2 *>(S + (uint32_t)min(max(j + 1, 0), last) * 2u);
+    const bool in0 = j >= 0 && j <= last, in1 = j + 1 >= 0 && j + 1 <= last;
+    return make_uint2(__builtin_amdgcn_alignbit(in1 ? l1.x : 0u, in0 ? l0.x : 0u, s), __builtin_amdgcn_alignbit(in1 ? l1.y : 0u, in0 ? l0.y : 0u, s));
+}
+
 template <int NP, bool REV>
 __device__ __forceinline__ uint32_t cells32(const uint32_t *__restrict__ A, uint32_t na, int32_t m,
                                             const uint32_t *__restrict__ B, uint32_t nb, int32_t n, int32_t row, int32_t col)
 {
     uint32_t mism = 0;
     const int32_t sa = REV ? m - 32 - row : row, sb = REV ? n - 32 - col : col;
+    if constexpr (NP == 2) {
+        const uint2 a = bits_at_dna(A, na, sa), b = bits_at_dna(B, nb, sb);
+        mism = (a.x ^ b.x) | (a.y ^ b.y);
+        return REV ? __brev(mism) : mism;
+    }
 #pragma unroll
     for (int p = 0; p < NP; p++) mism |= bits_at<NP>(A, na, sa, p) ^ bits_at<NP>(B, nb, sb, p);
     return REV ? __brev(mism) : mism;
