@@ -46,6 +46,7 @@ int malcs_gbuild_launch(malcs_ctx *ctx, int kind, uint4 *d_runs, const uint64_t 
                         const uint64_t *d_scratch_off, int32_t *d_out_words, uint64_t out_cap, unsigned long long *d_out_cursor,
                         int32_t *d_pair_out);
 int malcs_sweep_small_dmax();
+int malcs_sweep_pairs_per_wave(int64_t D);
 int malcs_gbuild_events_to_runs(malcs_ctx *ctx, int kind, const void *d_events, const uint64_t *d_ev_off, const uint32_t *d_ev_cnt,
                                 const uint32_t *d_slots, uint32_t n_slots, uint4 *d_runs, const uint64_t *d_run_off, uint32_t *d_run_cnt);
 
@@ -807,6 +808,13 @@ static int graph_batch(malcs_batch *b, const int64_t *shift, const int64_t *max_
         MALCS_HIP(d_shift.alloc(N));
         MALCS_HIP(hipMemcpyAsync(d_shift.p, shift, N * sizeof(int64_t), hipMemcpyHostToDevice, st));
         MALCS_HIP(malcs_sync(st));
+    }
+    {   // the one-wave sweeps take more pairs per wave the closer the pairs: by that number, if the list mixes them
+        std::vector<uint32_t> &P = sweeps[1].pairs;
+        bool mixed = false;
+        for (size_t s = 1; s < P.size() && !mixed; s++) mixed = malcs_sweep_pairs_per_wave(dist[P[s]]) != malcs_sweep_pairs_per_wave(dist[P[0]]);
+        if (mixed)
+            std::stable_sort(P.begin(), P.end(), [&](uint32_t x, uint32_t y) { return malcs_sweep_pairs_per_wave(dist[x]) > malcs_sweep_pairs_per_wave(dist[y]); });
     }
     for (int shape = 0; shape < 2; shape++) {
         sweep_set &S = sweeps[shape];

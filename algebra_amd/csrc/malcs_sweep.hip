@@ -25,6 +25,8 @@
 int malcs_graph_launch_compact(malcs_ctx *ctx, const void *d_events, const uint64_t *d_ev_off, const uint32_t *d_ev_n,
                                const uint64_t *d_out_off, uint32_t count, void *d_out);
 
+int malcs_sweep_pairs_per_wave(int64_t D);
+
 namespace {
 
 constexpr int LDS_DIAGS = 8192;
@@ -453,6 +455,247 @@ k_sweep_runs(const uint32_t *__restrict__ planes, const uint32_t *__restrict__ a
     if (threadIdx.x == 0) out_cnt[w] = lds_cnt;
 }
 
+// ---- several pairs per wave -------------------------------------------------------------------------------------
+// A budget step of the one-wave kernels above keeps as many lanes busy as the step has diagonals: d / 2 + 1 of 64 at
+// budget d, a sixth of the wave for a 1 kb window at distance 20 -- and the kernels are bound by the instructions they
+// issue, not by memory.  Here a wave is PPW groups of 64 / PPW lanes and a group does what the wave did above, for a pair
+// of its own: own diagonals (its share of the LDS array: the host sends a chunk here only if every pair's diagonals fit
+// it), own budget loop (the wave goes on until its last group is done), own counters.  What stays the wave's: the queue
+// of slides that outlast a lane's two words -- all 64 lanes finish them one after the other, with the parameters of the
+// pair the slide belongs to.  The arithmetic is that of k_sweep_reach / k_sweep_runs, statement by statement.
+template <int NP, bool REV>
+__device__ __forceinline__ void finish_slides_multi(sweep_queue<SMALL_THREADS> &q, const int32_t *q_lane, const uint32_t *A, uint32_t na, int32_t m,
+                                                    const uint32_t *B, uint32_t nb, int32_t n)
+{
+    const int32_t nq = q.n;
+    for (int32_t i = 0; i < nq; i++) {
+        // the pair of this slide: what its lane holds
+        const int src = q_lane[i];
+        const unsigned long long Ae = __shfl((unsigned long long)reinterpret_cast<uintptr_t>(A), src, 64);
+        const unsigned long long Be = __shfl((unsigned long long)reinterpret_cast<uintptr_t>(B), src, 64);
+        const uint32_t *Ai = reinterpret_cast<const uint32_t *>((uintptr_t)Ae), *Bi = reinterpret_cast<const uint32_t *>((uintptr_t)Be);
+        const uint32_t nai = __shfl(na, src, 64), nbi = __shfl(nb, src, 64);
+        const int32_t mi = __shfl(m, src, 64), ni = __shfl(n, src, 64);
+        const int32_t k = q.k[i], limit = min(mi, ni - k);
+        int32_t pos = q.pos[i];
+        if (threadIdx.x == 0) q.first[0] = NO_STOP;
+        __syncthreads();
+        for (uint32_t round = 0;; round++) {
+            if (threadIdx.x == 0) q.first[(round + 1u) % 3u] = NO_STOP;
+            const int32_t p = pos + 32 * (int32_t)threadIdx.x;
+            if (p < limit) {
+                uint32_t mism = cells32<NP, REV>(Ai, nai, mi, Bi, nbi, ni, p, p + k);
+                const int32_t valid = limit - p;
+                if (valid < 32) mism |= ~0u << valid;
+                if (mism) atomicMin(&q.first[round % 3u], p + (int32_t)__builtin_ctz(mism));
+            } else if (p - 32 < limit) {
+                atomicMin(&q.first[round % 3u], limit);
+            }
+            __syncthreads();
+            const int32_t f = q.first[round % 3u];
+            if (f != NO_STOP) { if (threadIdx.x == 0) q.stop[i] = f; break; }
+            pos += 32 * SMALL_THREADS;
+        }
+        __syncthreads();
+    }
+}
+
+template <int NP, bool REV, int PPW>
+__global__ void __launch_bounds__(SMALL_THREADS)
+k_sweep_reach_multi(const uint32_t *__restrict__ planes, const uint32_t *__restrict__ a_off, const uint32_t *__restrict__ a_len,
+                    const uint32_t *__restrict__ b_off, const uint32_t *__restrict__ b_len, const uint32_t *__restrict__ work, uint32_t count,
+                    const int32_t *__restrict__ caps, int32_t *__restrict__ tab, const uint64_t *__restrict__ tab_off, int32_t *__restrict__ dist_out)
+{
+    constexpr int LG = SMALL_THREADS / PPW, DGG = SMALL_DIAGS / PPW;
+    __shared__ int32_t lds_fr[SMALL_DIAGS];
+    __shared__ sweep_queue<SMALL_THREADS> q;
+    __shared__ int32_t q_lane[SMALL_THREADS * SWEEP_UNROLL];
+    const uint32_t g = threadIdx.x / LG, w = blockIdx.x * PPW + g;
+    const int32_t lt = (int32_t)(threadIdx.x % LG);
+    const bool valid = w < count;
+    const uint32_t pid = work[valid ? w : 0u];
+    const int32_t m = (int32_t)a_len[pid], n = (int32_t)b_len[pid], delta = n - m, cap = valid ? caps[w] : -1;
+    const uint32_t *A = planes + a_off[pid], *B = planes + b_off[pid];
+    const uint32_t na = ((uint32_t)m + 31u) >> 5, nb = ((uint32_t)n + 31u) >> 5;
+    const int32_t ndiag = 2 * cap + 3;                                        // (at most DGG: the host's condition for this kernel)
+    int32_t *FR = lds_fr + g * DGG;
+    int32_t *T = tab && valid ? tab + tab_off[w] : nullptr;
+    for (int32_t i = lt; i < min(ndiag, DGG); i += LG) {
+        const int32_t k = i - cap - 1;
+        FR[i] = (k < 0 ? -k : 0) - 1;
+    }
+    if (threadIdx.x == 0) { q.n = 0; q.first[0] = NO_STOP; }
+    __syncthreads();
+    int32_t found = -1;
+    bool running = valid && ndiag <= DGG && delta >= -cap && delta <= cap && cap >= 0;
+    for (int32_t d = 0; __any(running); d++) {
+        int32_t klo = max(-d, -m), khi = min(d, n);
+        if ((klo + d) & 1) klo++;
+        if ((khi + d) & 1) khi--;
+        const int32_t nk = running && khi >= klo ? (khi - klo) / 2 + 1 : 0;
+        for (int32_t base = 0; __any(base < nk); base += LG) {
+            const int32_t i = base + lt;
+            const bool mine = i < nk;
+            const int32_t k = klo + 2 * (mine ? i : 0), idx = k + cap + 1;
+            const int32_t limit = min(m, n - k);
+            int32_t stop = 0, pos = 0, slot = -1;
+            bool open = false;
+            if (nk > 0) {                                                     // (a group that is done reads nothing)
+                const int32_t prev = FR[idx];
+                stop = prev;
+                open = mine && prev < limit;
+                pos = min(max(max(FR[idx - 1], FR[idx + 1] + 1), prev + 1), limit);
+            }
+            bool queued = false;
+            if (open) {
+                uint32_t mm = cells32<NP, REV>(A, na, m, B, nb, n, pos, pos + k);
+                int32_t p = pos, st = NO_STOP;
+                for (int wi = 0;; wi++) {
+                    const int32_t left = limit - p;
+                    if (left < 32) mm |= left <= 0 ? ~0u : (~0u << left);
+                    if (mm) { st = p + (int32_t)__builtin_ctz(mm); break; }
+                    p += 32;
+                    if (wi + 1 == LOCAL_WORDS) break;
+                    mm = cells32<NP, REV>(A, na, m, B, nb, n, p, p + k);
+                }
+                stop = st;
+                if (st == NO_STOP) { slot = atomicAdd(&q.n, 1); q.pos[slot] = p; q.k[slot] = k; q_lane[slot] = (int32_t)threadIdx.x; queued = true; }
+            }
+            if (__syncthreads_or(queued)) {
+                finish_slides_multi<NP, REV>(q, q_lane, A, na, m, B, nb, n);
+                if (threadIdx.x == 0) q.n = 0;
+                __syncthreads();
+                if (slot >= 0) stop = q.stop[slot];
+            }
+            if (mine) {
+                FR[idx] = stop;                                               // own parity: nobody else reads it in this step
+                if (T) T[(int64_t)d * (d + 1) / 2 + (k + d) / 2] = stop;
+            }
+        }
+        __syncthreads();                                                      // budget d + 1 reads what budget d wrote
+        if (running) {
+            if (FR[delta + cap + 1] >= m) { found = d; running = false; }
+            else if (d + 1 > cap) running = false;
+        }
+    }
+    if (valid && lt == 0) dist_out[w] = found;
+}
+
+template <int NP, int PPW>
+__global__ void __launch_bounds__(SMALL_THREADS)
+k_sweep_runs_multi(const uint32_t *__restrict__ planes, const uint32_t *__restrict__ a_off, const uint32_t *__restrict__ a_len,
+                   const uint32_t *__restrict__ b_off, const uint32_t *__restrict__ b_len, const uint32_t *__restrict__ work, uint32_t count,
+                   const int32_t *__restrict__ dists, const int32_t *__restrict__ tab, const uint64_t *__restrict__ tab_off,
+                   uint4 *__restrict__ out, const uint64_t *__restrict__ out_off, const uint32_t *__restrict__ out_cap,
+                   uint32_t *__restrict__ out_cnt)
+{
+    constexpr int LG = SMALL_THREADS / PPW, DGG = SMALL_DIAGS / PPW;
+    __shared__ int32_t lds_fr[SMALL_DIAGS];
+    __shared__ sweep_queue<SMALL_THREADS> q;
+    __shared__ int32_t q_lane[SMALL_THREADS * SWEEP_UNROLL];
+    __shared__ uint32_t lds_cnt[PPW];
+    const uint32_t g = threadIdx.x / LG, w = blockIdx.x * PPW + g;
+    const int32_t lt = (int32_t)(threadIdx.x % LG);
+    const bool valid = w < count;
+    const uint32_t wv = valid ? w : 0u, pid = work[wv];
+    const int32_t m = (int32_t)a_len[pid], n = (int32_t)b_len[pid], delta = n - m, D = valid ? dists[w] : -1;
+    const uint32_t *A = planes + a_off[pid], *B = planes + b_off[pid];
+    const uint32_t na = ((uint32_t)m + 31u) >> 5, nb = ((uint32_t)n + 31u) >> 5;
+    const int32_t kmin = -((D - delta) / 2), kmax = (D + delta) / 2, ndiag = kmax - kmin + 3;
+    int32_t *FR = lds_fr + g * DGG;                                           // (ndiag <= DGG: the host's condition for this kernel)
+    const int32_t *T = tab + tab_off[wv];
+    uint4 *dst = out + out_off[wv];
+    const uint32_t cap = valid ? out_cap[w] : 0u;
+    bool running = valid && D >= 0 && ndiag <= DGG;
+    if (running)
+        for (int32_t i = lt; i < ndiag; i += LG) {
+            const int32_t k = kmin - 1 + i;
+            FR[i] = (k < 0 ? -k : 0) - 1;
+        }
+    if (threadIdx.x == 0) { q.n = 0; q.first[0] = NO_STOP; }
+    if (lt == 0) lds_cnt[g] = 0;
+    __syncthreads();
+    auto emit = [&](int32_t start, int32_t end, int32_t k, int32_t d) {
+        const uint32_t slot = atomicAdd(&lds_cnt[g], 1u);
+        if (slot < cap) dst[slot] = make_uint4((uint32_t)start, (uint32_t)(start + k), (uint32_t)(end - start), (uint32_t)((2 * end + k - d) / 2 - 1));
+    };
+    for (int32_t d = 0; __any(running); d++) {
+        const int32_t klo = max(-d, delta - (D - d)), khi = min(d, delta + (D - d));
+        const int32_t nk = running && khi >= klo ? (khi - klo) / 2 + 1 : 0;
+        for (int32_t base = 0; __any(base < nk); base += LG) {
+            const int32_t i = base + lt;
+            const bool mine = i < nk;
+            const int32_t k = klo + 2 * (mine ? i : 0), idx = k - kmin + 1;
+            const int32_t limit = min(m, n - k), dd = D - d, kk = delta - k;
+            int32_t prev = 0, stop = 0, slot = -1, x = 0, reach = 0;
+            bool active = false;
+            if (nk > 0) {
+                prev = FR[idx];
+                stop = prev;
+                active = mine && prev < limit;
+                x = min(max(max(FR[idx - 1], FR[idx + 1] + 1), prev + 1), limit);
+                reach = T[(int64_t)dd * (dd + 1) / 2 + (kk + dd) / 2];            // rows the sink reaches back on this diagonal
+            }
+            bool queued = false;
+            if (active) {
+                uint32_t mism = cells32<NP, false>(A, na, m, B, nb, n, x, x + k);
+                int32_t pos = x, st = NO_STOP;
+                for (int wi = 0;; wi++) {
+                    const int32_t left = limit - pos;
+                    if (left < 32) mism |= left <= 0 ? ~0u : (~0u << left);
+                    if (mism) { st = pos + (int32_t)__builtin_ctz(mism); break; }
+                    pos += 32;
+                    if (wi + 1 == LOCAL_WORDS) break;
+                    mism = cells32<NP, false>(A, na, m, B, nb, n, pos, pos + k);
+                }
+                stop = st;
+                if (st == NO_STOP) { slot = atomicAdd(&q.n, 1); q.pos[slot] = pos; q.k[slot] = k; q_lane[slot] = (int32_t)threadIdx.x; queued = true; }
+            }
+            if (__syncthreads_or(queued)) {
+                finish_slides_multi<NP, false>(q, q_lane, A, na, m, B, nb, n);
+                if (threadIdx.x == 0) q.n = 0;
+                __syncthreads();
+                if (slot >= 0) stop = q.stop[slot];
+            }
+            if (mine) FR[idx] = stop;                                         // own parity: nobody else reads it in this step
+            const int32_t lo = max(prev + 1, m - reach);                      // first corner the sink reaches
+            if (!active || stop < lo) continue;                               // (the wave meets again at the loop's condition)
+            const int32_t s0 = min(lo, x);
+            int32_t s = s0;
+            while (s > prev + 1) {
+                const int32_t ws = s - 32;
+                uint32_t mism = cells32<NP, false>(A, na, m, B, nb, n, ws, ws + k);
+                const int32_t before = prev + 1 - ws;
+                if (before > 0) mism |= before >= 32 ? ~0u : ((1u << before) - 1u);
+                if (mism) { s = ws + 32 - (int32_t)__builtin_clz(mism); break; }
+                s = ws;
+            }
+            int32_t pos = s, run_start = s;
+            uint32_t in_run = 0;
+            while (pos < x) {
+                const uint32_t mism = cells32<NP, false>(A, na, m, B, nb, n, pos, pos + k);
+                const int32_t nbits = min(32, x - pos);
+                const uint32_t low = nbits == 32 ? ~0u : ((1u << nbits) - 1u);
+                const uint32_t match = ~mism & low;
+                uint32_t turn = (match ^ ((match << 1) | in_run)) & low;
+                while (turn) {
+                    const int32_t t = __builtin_ctz(turn);
+                    turn &= turn - 1u;
+                    if ((match >> t) & 1u) run_start = pos + t;
+                    else if (pos + t >= lo) emit(run_start, pos + t, k, d);
+                }
+                in_run = (match >> (nbits - 1)) & 1u;
+                pos += 32;
+            }
+            const int32_t fs = in_run ? run_start : x;
+            if (stop > fs) emit(fs, stop, k, d);
+        }
+        __syncthreads();                                                      // budget d + 1 reads what budget d wrote
+        if (running && d + 1 > D) running = false;
+    }
+    if (valid && lt == 0) out_cnt[w] = lds_cnt[g];
+}
+
 // device memory of a call, from the context's pool (a hipMalloc costs a fraction of a millisecond and a hipFree waits for
 // the device; a sweep over a C2 batch used to make fourteen of each)
 template <typename T> struct dbuf {
@@ -575,8 +818,19 @@ namespace {
 
 template <int NP>
 int launch_reach(malcs_batch *b, bool small, bool rev, uint32_t count, const uint32_t *d_work, const int32_t *d_caps, int32_t *d_fr,
-                 const uint64_t *d_fr_off, int32_t *d_tab, const uint64_t *d_tab_off, int32_t *d_dist)
+                 const uint64_t *d_fr_off, int32_t *d_tab, const uint64_t *d_tab_off, int32_t *d_dist, int ppw = 1)
 {
+#define SWEEP_REACH_MULTI(REV, PPW)                                                                                         \
+    hipLaunchKernelGGL((k_sweep_reach_multi<NP, REV, PPW>), dim3((count + PPW - 1) / PPW), dim3(SMALL_THREADS), 0, b->ctx->stream, b->d_planes, \
+                       b->d_a_off, b->d_a_len, b->d_b_off, b->d_b_len, d_work, count, d_caps, d_tab, d_tab_off, d_dist)
+    if (small && ppw > 1) {
+        if (ppw == 8)      { if (rev) SWEEP_REACH_MULTI(true, 8); else SWEEP_REACH_MULTI(false, 8); }
+        else if (ppw == 4) { if (rev) SWEEP_REACH_MULTI(true, 4); else SWEEP_REACH_MULTI(false, 4); }
+        else               { if (rev) SWEEP_REACH_MULTI(true, 2); else SWEEP_REACH_MULTI(false, 2); }
+        MALCS_HIP(hipGetLastError());
+        return MALCS_OK;
+    }
+#undef SWEEP_REACH_MULTI
 #define SWEEP_REACH(REV, TH, DG)                                                                                            \
     hipLaunchKernelGGL((k_sweep_reach<NP, REV, TH, DG>), dim3(count), dim3(TH), 0, b->ctx->stream, b->d_planes, b->d_a_off, b->d_a_len, \
                        b->d_b_off, b->d_b_len, d_work, d_caps, d_fr, d_fr_off, d_tab, d_tab_off, d_dist)
@@ -588,13 +842,13 @@ int launch_reach(malcs_batch *b, bool small, bool rev, uint32_t count, const uin
 }
 
 int launch_reach_any(malcs_batch *b, bool small, bool rev, uint32_t count, const uint32_t *d_work, const int32_t *d_caps, int32_t *d_fr,
-                     const uint64_t *d_fr_off, int32_t *d_tab, const uint64_t *d_tab_off, int32_t *d_dist)
+                     const uint64_t *d_fr_off, int32_t *d_tab, const uint64_t *d_tab_off, int32_t *d_dist, int ppw = 1)
 {
     switch (b->n_planes) {
-    case 2: return launch_reach<2>(b, small, rev, count, d_work, d_caps, d_fr, d_fr_off, d_tab, d_tab_off, d_dist);
-    case 3: return launch_reach<3>(b, small, rev, count, d_work, d_caps, d_fr, d_fr_off, d_tab, d_tab_off, d_dist);
-    case 4: return launch_reach<4>(b, small, rev, count, d_work, d_caps, d_fr, d_fr_off, d_tab, d_tab_off, d_dist);
-    case 8: return launch_reach<8>(b, small, rev, count, d_work, d_caps, d_fr, d_fr_off, d_tab, d_tab_off, d_dist);
+    case 2: return launch_reach<2>(b, small, rev, count, d_work, d_caps, d_fr, d_fr_off, d_tab, d_tab_off, d_dist, ppw);
+    case 3: return launch_reach<3>(b, small, rev, count, d_work, d_caps, d_fr, d_fr_off, d_tab, d_tab_off, d_dist, ppw);
+    case 4: return launch_reach<4>(b, small, rev, count, d_work, d_caps, d_fr, d_fr_off, d_tab, d_tab_off, d_dist, ppw);
+    case 8: return launch_reach<8>(b, small, rev, count, d_work, d_caps, d_fr, d_fr_off, d_tab, d_tab_off, d_dist, ppw);
     }
     malcs_set_error("unsupported plane count %d", b->n_planes);
     return MALCS_ERR_ARG;
@@ -603,9 +857,18 @@ int launch_reach_any(malcs_batch *b, bool small, bool rev, uint32_t count, const
 template <int NP>
 int launch_runs(malcs_batch *b, bool small, uint32_t count, const uint32_t *d_work, const int32_t *d_dists, int32_t *d_fr, const uint64_t *d_fr_off,
                 const int32_t *d_tab, const uint64_t *d_tab_off, uint4 *d_out, const uint64_t *d_out_off, const uint32_t *d_out_cap,
-                uint32_t *d_out_cnt)
+                uint32_t *d_out_cnt, int ppw = 1)
 {
-    if (small) hipLaunchKernelGGL((k_sweep_runs<NP, SMALL_THREADS, SMALL_DIAGS>), dim3(count), dim3(SMALL_THREADS), 0, b->ctx->stream, b->d_planes,
+    if (small && ppw == 8)
+        hipLaunchKernelGGL((k_sweep_runs_multi<NP, 8>), dim3((count + 7) / 8), dim3(SMALL_THREADS), 0, b->ctx->stream, b->d_planes, b->d_a_off,
+                           b->d_a_len, b->d_b_off, b->d_b_len, d_work, count, d_dists, d_tab, d_tab_off, d_out, d_out_off, d_out_cap, d_out_cnt);
+    else if (small && ppw == 4)
+        hipLaunchKernelGGL((k_sweep_runs_multi<NP, 4>), dim3((count + 3) / 4), dim3(SMALL_THREADS), 0, b->ctx->stream, b->d_planes, b->d_a_off,
+                           b->d_a_len, b->d_b_off, b->d_b_len, d_work, count, d_dists, d_tab, d_tab_off, d_out, d_out_off, d_out_cap, d_out_cnt);
+    else if (small && ppw == 2)
+        hipLaunchKernelGGL((k_sweep_runs_multi<NP, 2>), dim3((count + 1) / 2), dim3(SMALL_THREADS), 0, b->ctx->stream, b->d_planes, b->d_a_off,
+                           b->d_a_len, b->d_b_off, b->d_b_len, d_work, count, d_dists, d_tab, d_tab_off, d_out, d_out_off, d_out_cap, d_out_cnt);
+    else if (small) hipLaunchKernelGGL((k_sweep_runs<NP, SMALL_THREADS, SMALL_DIAGS>), dim3(count), dim3(SMALL_THREADS), 0, b->ctx->stream, b->d_planes,
                                   b->d_a_off, b->d_a_len, b->d_b_off, b->d_b_len, d_work, d_dists, d_fr, d_fr_off, d_tab, d_tab_off, d_out,
                                   d_out_off, d_out_cap, d_out_cnt);
     else hipLaunchKernelGGL((k_sweep_runs<NP, BIG_THREADS, BIG_DIAGS>), dim3(count), dim3(BIG_THREADS), 0, b->ctx->stream, b->d_planes,
@@ -613,6 +876,18 @@ int launch_runs(malcs_batch *b, bool small, uint32_t count, const uint32_t *d_wo
                             d_out_off, d_out_cap, d_out_cnt);
     MALCS_HIP(hipGetLastError());
     return MALCS_OK;
+}
+
+// pairs per wave of the one-wave sweeps: as many as the widest pair of the chunk leaves room for (its diagonals in its
+// group's share of the LDS array); MALCS_SWEEP_PPW caps it (1: the one-pair kernels)
+int sweep_ppw(bool small, const std::vector<int64_t> &ndiag)
+{
+    if (!small || ndiag.empty()) return 1;
+    int64_t widest = 0;
+    for (int64_t v : ndiag) widest = std::max(widest, v);
+    int ppw = widest <= SMALL_DIAGS / 8 ? 8 : widest <= SMALL_DIAGS / 4 ? 4 : widest <= SMALL_DIAGS / 2 ? 2 : 1;
+    if (const char *e = getenv("MALCS_SWEEP_PPW")) ppw = std::min(ppw, atoi(e) >= 8 ? 8 : atoi(e) >= 4 ? 4 : atoi(e) >= 2 ? 2 : 1);
+    return ppw;
 }
 
 // scratch for FR: pairs whose diagonals do not fit LDS
@@ -693,6 +968,8 @@ int malcs_sweep_optimal_runs(malcs_batch *b, bool small, const std::vector<uint3
                                           : dist[work[end]];
             const uint64_t need = (uint64_t)(D + 1) * (uint64_t)(D + 2) / 2;
             if (end > pos && tab_total + need > budget) break;
+            // a chunk of one-wave sweeps holds pairs of one width: its widest pair decides how many pairs share a wave
+            if (small && end > pos && malcs_sweep_pairs_per_wave(D) != malcs_sweep_pairs_per_wave(dists[0])) break;
             if (need > budget) {
                 malcs_set_error("pair %u at distance %lld needs %llu MiB of reach table; the device has %llu MiB free", work[end],
                                 (long long)D, (unsigned long long)(need >> 18), (unsigned long long)(free_b >> 20));
@@ -723,7 +1000,8 @@ int malcs_sweep_optimal_runs(malcs_batch *b, bool small, const std::vector<uint3
         // entry the forward pass looks up has been written: skip the fill)
         if (!unknown_cap) MALCS_HIP(hipMemsetAsync(d_tab.p, 0xff, tab_total * 4ull, st));
         MALCS_HIP(hipEventRecord(ctx->ev0, st));
-        int rc = launch_reach_any(b, small, true, cnt, d_work.p, d_dists.p, d_fr.p, d_fr_off.p, d_tab.p, d_tab_off.p, d_found.p);
+        int rc = launch_reach_any(b, small, true, cnt, d_work.p, d_dists.p, d_fr.p, d_fr_off.p, d_tab.p, d_tab_off.p, d_found.p,
+                                  sweep_ppw(small, nd_back));
         if (rc) return rc;
         MALCS_HIP(hipEventRecord(ctx->ev1, st));
         std::vector<int32_t> found(cnt);
@@ -779,6 +1057,7 @@ int malcs_sweep_optimal_runs(malcs_batch *b, bool small, const std::vector<uint3
             off[f] = total; total += cap[f];
         }
         MALCS_HIP(malcs_h2d(st, d_fr_off.p, fr_off_f.data(), cntf * 8ull));
+        const int ppw_f = sweep_ppw(small, nd_fwd);
         for (int attempt = 0;; attempt++) {
             d_out.release();
             if (d_out.alloc(total)) { malcs_set_error("device allocation failed (%llu runs)", (unsigned long long)total); return MALCS_ERR_NOMEM; }
@@ -786,10 +1065,10 @@ int malcs_sweep_optimal_runs(malcs_batch *b, bool small, const std::vector<uint3
             MALCS_HIP(malcs_h2d(st, d_out_off.p, off.data(), cntf * 8ull));
             MALCS_HIP(hipEventRecord(ctx->ev1, st));
             switch (b->n_planes) {
-            case 2: rc = launch_runs<2>(b, small, cntf, d_work.p, d_dists.p, d_fr.p, d_fr_off.p, d_tab.p, d_tab_off.p, d_out.p, d_out_off.p, d_cap.p, d_cnt.p); break;
-            case 3: rc = launch_runs<3>(b, small, cntf, d_work.p, d_dists.p, d_fr.p, d_fr_off.p, d_tab.p, d_tab_off.p, d_out.p, d_out_off.p, d_cap.p, d_cnt.p); break;
-            case 4: rc = launch_runs<4>(b, small, cntf, d_work.p, d_dists.p, d_fr.p, d_fr_off.p, d_tab.p, d_tab_off.p, d_out.p, d_out_off.p, d_cap.p, d_cnt.p); break;
-            case 8: rc = launch_runs<8>(b, small, cntf, d_work.p, d_dists.p, d_fr.p, d_fr_off.p, d_tab.p, d_tab_off.p, d_out.p, d_out_off.p, d_cap.p, d_cnt.p); break;
+            case 2: rc = launch_runs<2>(b, small, cntf, d_work.p, d_dists.p, d_fr.p, d_fr_off.p, d_tab.p, d_tab_off.p, d_out.p, d_out_off.p, d_cap.p, d_cnt.p, ppw_f); break;
+            case 3: rc = launch_runs<3>(b, small, cntf, d_work.p, d_dists.p, d_fr.p, d_fr_off.p, d_tab.p, d_tab_off.p, d_out.p, d_out_off.p, d_cap.p, d_cnt.p, ppw_f); break;
+            case 4: rc = launch_runs<4>(b, small, cntf, d_work.p, d_dists.p, d_fr.p, d_fr_off.p, d_tab.p, d_tab_off.p, d_out.p, d_out_off.p, d_cap.p, d_cnt.p, ppw_f); break;
+            case 8: rc = launch_runs<8>(b, small, cntf, d_work.p, d_dists.p, d_fr.p, d_fr_off.p, d_tab.p, d_tab_off.p, d_out.p, d_out_off.p, d_cap.p, d_cnt.p, ppw_f); break;
             default: malcs_set_error("unsupported plane count %d", b->n_planes); rc = MALCS_ERR_ARG;
             }
             if (rc) return rc;
@@ -847,3 +1126,11 @@ int malcs_sweep_optimal_runs(malcs_batch *b, bool small, const std::vector<uint3
 }
 
 int malcs_sweep_small_dmax() { return SMALL_DMAX; }
+
+// pairs per wave of the one-wave sweeps at distance D (the backward sweep's 2 D + 3 diagonals in a group's share of LDS):
+// the caller orders its list by this number, so that a few distant pairs do not take the whole batch to one pair per wave
+int malcs_sweep_pairs_per_wave(int64_t D)
+{
+    const int64_t ndiag = 2 * D + 3;
+    return ndiag <= SMALL_DIAGS / 8 ? 8 : ndiag <= SMALL_DIAGS / 4 ? 4 : ndiag <= SMALL_DIAGS / 2 ? 2 : 1;
+}

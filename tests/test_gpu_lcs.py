@@ -931,6 +931,48 @@ def test_graphs_built_on_the_device_match_the_host_half(native, path, monkeypatc
         host.close()
 
 
+@pytest.mark.parametrize("nsym", [4, 20])
+def test_sweeps_with_several_pairs_per_wave(native, nsym, monkeypatch):
+    """The one-wave sweeps take 8, 4 or 2 pairs per wave when the diagonals of every pair of a chunk fit a group's share
+    of LDS (k_sweep_reach_multi / k_sweep_runs_multi); MALCS_SWEEP_PPW caps the number.  Same runs, same graphs for
+    every cap -- on pairs from identical to unrelated, empty and one-symbol sequences, slides that outlast a lane's two
+    words (identical 2.5 kb pairs), a pair count that leaves the last wave's groups empty -- and the oracle's graphs."""
+    from oracle import oracle as O
+    monkeypatch.setenv("MALCS_SWEEP_MIN_ROWS", "1")
+    monkeypatch.setenv("MALCS_SWEEP_RATIO", "0")
+    rs = np.random.RandomState(77 + nsym)
+    syms, a_off, a_len, b_off, b_len = _window_class_batch(rs, 1203, nsym)
+    a_len, b_len = a_len.copy(), b_len.copy()
+    a_len[5], b_len[6], a_len[7], b_len[7] = 0, 0, 0, 0                      # empty on either side, on both
+    a_len[9], b_len[10] = 1, 1
+    ctx = native.default_context()
+    results = {}
+    for ppw in ("1", "2", "4", "8"):
+        monkeypatch.setenv("MALCS_SWEEP_PPW", ppw)
+        batch = native.Batch(ctx, syms, a_off, a_len, b_off, b_len, nsym)
+        results[ppw] = batch.graphs()
+        batch.close()
+    try:
+        one = results["1"]
+        for ppw in ("2", "4", "8"):
+            got = results[ppw]
+            assert np.array_equal(got.distance, one.distance) and np.array_equal(got.counts, one.counts), ppw
+            assert np.array_equal(got.supremal, one.supremal), ppw
+            for i in range(1203):
+                assert np.array_equal(got.runs(i), one.runs(i)), (ppw, i)
+                assert np.array_equal(got.nodes(i), one.nodes(i)) and np.array_equal(got.edges(i), one.edges(i)), (ppw, i)
+        got = results["8"]
+        for i in list(range(0, 12)) + list(range(12, 1203, 40)):
+            a = syms[int(a_off[i]):int(a_off[i]) + int(a_len[i])]
+            b = syms[int(b_off[i]):int(b_off[i]) + int(b_len[i])]
+            ref = O.lcs_graph(a, b, 0)
+            assert int(got.distance[i]) == O.edit_distance(a, b), i
+            assert tuple(got.supremal[i]) == ref.supremal and np.array_equal(got.nodes(i), ref.nodes) and np.array_equal(got.edges(i), ref.edges), i
+    finally:
+        for r in results.values():
+            r.close()
+
+
 @pytest.mark.parametrize("path", ["sweep", "band"])
 def test_c5_ii_one_megabase_two_percent(native, path, monkeypatch):
     """BASELINE config 5 (ii): one 1 Mb pair at 2 % indels (D about 20 000) on both device paths.
