@@ -45,6 +45,8 @@ int malcs_gbuild_launch(malcs_ctx *ctx, int kind, uint4 *d_runs, const uint64_t 
                         const uint32_t *d_b_len, const int32_t *d_dist, const int64_t *d_shift, int32_t *d_scratch,
                         const uint64_t *d_scratch_off, int32_t *d_out_words, uint64_t out_cap, unsigned long long *d_out_cursor,
                         int32_t *d_pair_out);
+int malcs_gbuild_order(malcs_ctx *ctx, int kind, uint4 *d_runs, const uint64_t *d_run_off, const uint32_t *d_run_cnt, const uint32_t *d_pids,
+                       const uint32_t *d_slots, uint32_t n_slots, const uint32_t *d_a_len, const uint32_t *d_b_len);
 int malcs_sweep_small_dmax();
 int malcs_sweep_pairs_per_wave(int64_t D);
 int malcs_gbuild_events_to_runs(malcs_ctx *ctx, int kind, const void *d_events, const uint64_t *d_ev_off, const uint32_t *d_ev_cnt,
@@ -603,10 +605,28 @@ static int gbuild_hook(void *user_, const malcs_sweep_chunk &c)
     struct event_set {
         std::vector<hipEvent_t> ev;
         ~event_set() { for (hipEvent_t e : ev) (void)hipEventDestroy(e); }
-    } done;
+    } done, ordered;
     pinned_vec<unsigned long long> grown;
     grown.resize(groups.size());
     MALCS_HIP(hipEventRecord(ctx->ev1, st));
+    // the runs in the reference's order first, every slot's in place: they are final then (what the handle exposes, and
+    // what the host half builds from if a kernel gives a pair up) and go home on the second stream, under the construction
+    {
+        int rc = malcs_gbuild_order(ctx, 0, c.d_runs, c.d_run_off, c.d_run_cnt, c.d_pids, d_slots.p, (uint32_t)(tiny.size() + small.size()),
+                                    u.b->d_a_len, u.b->d_b_len);
+        if (!rc) rc = malcs_gbuild_order(ctx, 2, c.d_runs, c.d_run_off, c.d_run_cnt, c.d_pids, d_slots.p + tiny.size() + small.size(),
+                                         (uint32_t)big.size(), u.b->d_a_len, u.b->d_b_len);
+        if (rc) return rc;
+        if (c.host_runs && c.n_runs && c.runs_home) {
+            hipEvent_t e = nullptr;
+            MALCS_HIP(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+            ordered.ev.push_back(e);
+            MALCS_HIP(hipEventRecord(e, st));
+            MALCS_HIP(hipStreamWaitEvent(ctx->copy_stream, e, 0));
+            MALCS_HIP(hipMemcpyAsync(c.host_runs, c.d_runs, c.n_runs * 16ull, hipMemcpyDeviceToHost, ctx->copy_stream));
+            *c.runs_home = true;                                          // (both streams are drained before this function returns)
+        }
+    }
     for (size_t k = 0; k < groups.size(); k++) {
         const int rc = malcs_gbuild_launch(ctx, groups[k].kind, c.d_runs, c.d_run_off, c.d_run_cnt, c.d_pids, d_slots.p + groups[k].first,
                                            (uint32_t)groups[k].count, u.b->d_a_len, u.b->d_b_len, u.b->d_dist, u.d_shift, d_scratch.p,
@@ -976,14 +996,16 @@ static int graph_batch(malcs_batch *b, const int64_t *shift, const int64_t *max_
                         if (rc) return rc;
                         MALCS_HIP(malcs_sync(st));                               // (`slots` and `run_off` are locals the copies read)
                         gbuild_user user{b, out, shift, d_shift.p, nullptr};
-                        const malcs_sweep_chunk chunk{d_runs.p, d_runoff.p, d_runcnt.p, d_work.p, cnt, work.data(), run_cnt.data(), run_off.data(), nullptr};
-                        rc = gbuild_hook(&user, chunk);
-                        if (rc) return rc;
                         // the runs, sorted by the graph kernels, for the handle (runs(i)) of the pairs that were built there
                         bv_runs.emplace_back();
                         pinned_vec<uint32_t> &flat = bv_runs.back();
                         flat.resize((size_t)runs_total * 4);
-                        MALCS_HIP(hipMemcpyAsync(flat.data(), d_runs.p, runs_total * 16ull, hipMemcpyDeviceToHost, st));
+                        bool runs_home = false;
+                        const malcs_sweep_chunk chunk{d_runs.p, d_runoff.p, d_runcnt.p, d_work.p, cnt, work.data(), run_cnt.data(), run_off.data(), nullptr,
+                                                      flat.data(), runs_total, &runs_home};
+                        rc = gbuild_hook(&user, chunk);
+                        if (rc) return rc;
+                        if (!runs_home) MALCS_HIP(hipMemcpyAsync(flat.data(), d_runs.p, runs_total * 16ull, hipMemcpyDeviceToHost, st));
                         MALCS_HIP(malcs_sync(st));
                         for (uint32_t s = 0; s < cnt; s++) {
                             pair_graph &G = out->g[work[s]];

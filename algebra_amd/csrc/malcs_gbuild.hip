@@ -8,10 +8,12 @@
 // source, edges in Node.edges order).  What comes back to the host per pair is the finished node / edge arrays; the
 // host neither sorts nor links anything for these pairs.
 //
-// One wave per pair.
-//   * ordering: lane-parallel.  Every lane computes the sort keys of its runs and their ranks by counting the smaller
-//     keys (R^2 / 64 comparisons per lane against keys in LDS; R is a few dozen for a 1 kb window, at most 1 024 here);
-//   * construction: malcs_graph_core.hpp, the same source the host half compiles (so the two cannot drift apart), run
+// One wave per pair, two kernels.
+//   * ordering (k_order_runs): lane-parallel.  Every lane computes the sort keys of its runs and their ranks by counting
+//     the smaller keys (R^2 / 64 comparisons per lane against keys in LDS; R is a few dozen for a 1 kb window, at most
+//     1 024 here) and puts them back in place: from then on the runs are final and travel home on the context's second
+//     stream while the graphs are built;
+//   * construction (k_graph_build): malcs_graph_core.hpp, the same source the host half compiles (so the two cannot drift apart), run
 //     by lane 0 on an arena in LDS (graphs of <= 64 runs; everything is a few dependent LDS accesses per step) or in a
 //     per-pair stretch of global scratch (up to 1 024 runs).  The construction is a chain of dependent list operations:
 //     its parallelism is across the pairs of a batch (thousands of waves in flight), not inside a pair;
@@ -39,18 +41,55 @@ __device__ __forceinline__ void run_key(const int4 r, int32_t delta, uint64_t &k
     k2 = ((uint64_t)(uint32_t)(dk + 0x40000000) << 32) | (uint32_t)r.x;
 }
 
+// The ordering alone, for every slot of a list, ahead of the construction: the runs are final after it (sorted in
+// place), so that they travel home while the graphs are built (k_graph_build reads them as they lie).  Slots with no runs or more than RCAP are left alone (k_graph_build gives them up).
+template <int RCAP>
+__global__ void __launch_bounds__(64)
+k_order_runs(uint4 *__restrict__ runs, const uint64_t *__restrict__ run_off, const uint32_t *__restrict__ run_cnt,
+             const uint32_t *__restrict__ pids, const uint32_t *__restrict__ slots, uint32_t n_slots,
+             const uint32_t *__restrict__ a_len, const uint32_t *__restrict__ b_len)
+{
+    __shared__ uint64_t key1[RCAP], key2[RCAP];
+    if (blockIdx.x >= n_slots) return;
+    const uint32_t slot = slots[blockIdx.x], lane = threadIdx.x;
+    const uint32_t R = run_cnt[slot], pid = pids[slot];
+    if (R < 2 || R > (uint32_t)RCAP) return;
+    const int32_t delta = (int32_t)b_len[pid] - (int32_t)a_len[pid];
+    uint4 *mine = runs + run_off[slot];
+    constexpr int PER = (RCAP + 63) / 64;
+    uint4 held[PER];
+#pragma unroll
+    for (int t = 0; t < PER; t++) {
+        const uint32_t i = lane + 64u * t;
+        if (i < R) {
+            held[t] = mine[i];
+            run_key(make_int4((int)held[t].x, (int)held[t].y, (int)held[t].z, (int)held[t].w), delta, key1[i], key2[i]);
+        }
+    }
+    __syncthreads();                                                         // every run is in a register before any is overwritten
+#pragma unroll
+    for (int t = 0; t < PER; t++) {
+        const uint32_t i = lane + 64u * t;
+        if (i < R) {
+            const uint64_t a1 = key1[i], a2 = key2[i];
+            uint32_t rank = 0;
+            for (uint32_t j = 0; j < R; j++) rank += (key1[j] < a1 || (key1[j] == a1 && key2[j] < a2)) ? 1u : 0u;
+            mine[rank] = held[t];
+        }
+    }
+}
+
 // RCAP: runs a pair may have; NC / EC / LC: capacities of the LDS arena (LDS_ARENA) -- otherwise the arena is the slot's
 // stretch of `scratch`, sized by the host from the slot's run count
 template <int RCAP, bool LDS_ARENA, int NC, int EC, int LC>
 __global__ void __launch_bounds__(64)
-k_graph_build(uint4 *__restrict__ runs, const uint64_t *__restrict__ run_off, const uint32_t *__restrict__ run_cnt,
+k_graph_build(const uint4 *__restrict__ runs, const uint64_t *__restrict__ run_off, const uint32_t *__restrict__ run_cnt,
               const uint32_t *__restrict__ pids, const uint32_t *__restrict__ slots, uint32_t n_slots,
               const uint32_t *__restrict__ a_len, const uint32_t *__restrict__ b_len, const int32_t *__restrict__ dist,
               const int64_t *__restrict__ shift, int32_t *__restrict__ scratch, const uint64_t *__restrict__ scratch_off,
               int32_t *__restrict__ out_words, unsigned long long out_cap, unsigned long long *__restrict__ out_cursor,
               int32_t *__restrict__ pair_out)
 {
-    __shared__ uint64_t key1[RCAP], key2[RCAP];
     __shared__ int32_t sorted[4 * RCAP];
     __shared__ int32_t arena_mem[LDS_ARENA ? (9 * NC + 6 * EC + 2 * LC) : 1];
     __shared__ int32_t bcast[4];
@@ -59,26 +98,14 @@ k_graph_build(uint4 *__restrict__ runs, const uint64_t *__restrict__ run_off, co
     const uint32_t R = run_cnt[slot], pid = pids[slot];
     int32_t *po = pair_out + (size_t)slot * PAIR_OUT;
     if (R == 0 || R > (uint32_t)RCAP) { if (lane == 0) { po[0] = 1; po[9] = (int32_t)R; } return; }
-    const int32_t m = (int32_t)a_len[pid], n = (int32_t)b_len[pid], delta = n - m;
-    uint4 *mine = runs + run_off[slot];
-    // keys of this lane's runs, then their ranks: the number of runs with a smaller key (keys are distinct)
+    const int32_t m = (int32_t)a_len[pid], n = (int32_t)b_len[pid];
+    const uint4 *mine = runs + run_off[slot];
+    // the runs lie in the reference's order (k_order_runs has been here)
     for (uint32_t i = lane; i < R; i += 64) {
         const uint4 u = mine[i];
-        run_key(make_int4((int)u.x, (int)u.y, (int)u.z, (int)u.w), delta, key1[i], key2[i]);
+        sorted[4 * i] = (int32_t)u.x; sorted[4 * i + 1] = (int32_t)u.y; sorted[4 * i + 2] = (int32_t)u.z; sorted[4 * i + 3] = (int32_t)u.w;
     }
     __syncthreads();
-    for (uint32_t i = lane; i < R; i += 64) {
-        const uint64_t a1 = key1[i], a2 = key2[i];
-        uint32_t rank = 0;
-        for (uint32_t j = 0; j < R; j++) rank += (key1[j] < a1 || (key1[j] == a1 && key2[j] < a2)) ? 1u : 0u;
-        const uint4 u = mine[i];
-        sorted[4 * rank] = (int32_t)u.x; sorted[4 * rank + 1] = (int32_t)u.y; sorted[4 * rank + 2] = (int32_t)u.z; sorted[4 * rank + 3] = (int32_t)u.w;
-    }
-    __syncthreads();
-    // the runs go back in order: they are the `runs` the handle exposes, and what the host half builds from if this
-    // kernel has to give the pair up
-    for (uint32_t i = lane; i < R; i += 64)
-        mine[i] = make_uint4((uint32_t)sorted[4 * i], (uint32_t)sorted[4 * i + 1], (uint32_t)sorted[4 * i + 2], (uint32_t)sorted[4 * i + 3]);
     if (lane == 0) {
         malcs_core::arena A;
         if (LDS_ARENA) malcs_core::arena_bind(A, arena_mem, NC, EC, LC);
@@ -185,6 +212,17 @@ int malcs_gbuild_launch(malcs_ctx *ctx, int kind, uint4 *d_runs, const uint64_t 
         hipLaunchKernelGGL((k_graph_build<1024, false, 1, 1, 1>), dim3(n_slots), dim3(64), 0, ctx->stream, d_runs, d_run_off, d_run_cnt,
                            d_pids, d_slots, n_slots, d_a_len, d_b_len, d_dist, d_shift, d_scratch, d_scratch_off, d_out_words,
                            (unsigned long long)out_cap, d_out_cursor, d_pair_out);
+    MALCS_HIP(hipGetLastError());
+    return MALCS_OK;
+}
+
+// the runs of the slots of a list in the reference's order (kind as above: 0 and 1 at most 64 runs, 2 at most 1 024)
+int malcs_gbuild_order(malcs_ctx *ctx, int kind, uint4 *d_runs, const uint64_t *d_run_off, const uint32_t *d_run_cnt, const uint32_t *d_pids,
+                       const uint32_t *d_slots, uint32_t n_slots, const uint32_t *d_a_len, const uint32_t *d_b_len)
+{
+    if (!n_slots) return MALCS_OK;
+    if (kind < 2) hipLaunchKernelGGL((k_order_runs<64>), dim3(n_slots), dim3(64), 0, ctx->stream, d_runs, d_run_off, d_run_cnt, d_pids, d_slots, n_slots, d_a_len, d_b_len);
+    else hipLaunchKernelGGL((k_order_runs<1024>), dim3(n_slots), dim3(64), 0, ctx->stream, d_runs, d_run_off, d_run_cnt, d_pids, d_slots, n_slots, d_a_len, d_b_len);
     MALCS_HIP(hipGetLastError());
     return MALCS_OK;
 }

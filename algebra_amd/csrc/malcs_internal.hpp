@@ -262,11 +262,14 @@ int malcs_dist_launch_list(hipStream_t st, int n_planes, int W, int L, const uin
 // malcs_sweep.hip
 // A chunk of pairs whose optimal runs have just been compacted in device memory (before they are copied to the host):
 // slot f has runs d_runs[run_off[f] .. + cnt[f]) = {row, col, length, level}, belongs to pair pids[f] and to entry
-// work_index[f] of the caller's work list.
+// work_index[f] of the caller's work list.  host_runs (pinned, n_runs * 4 words; may be null): where the caller wants
+// the chunk's runs -- a hook that leaves them final before it is done may send them there itself, on a stream of its
+// own, and says so in *runs_home (the caller then does not copy them again).
 struct malcs_sweep_chunk {
     uint4 *d_runs; const uint64_t *d_run_off; const uint32_t *d_run_cnt; const uint32_t *d_pids;
     uint32_t count;
     const uint32_t *pids, *cnt; const uint64_t *run_off, *work_index;      // host copies
+    uint32_t *host_runs; uint64_t n_runs; bool *runs_home;
 };
 typedef int (*malcs_sweep_hook)(void *user, const malcs_sweep_chunk &chunk);
 int malcs_sweep_distances(malcs_batch *b, const std::vector<uint32_t> &pairs, int32_t cap, std::vector<int32_t> &out);

@@ -1099,16 +1099,18 @@ int malcs_sweep_optimal_runs(malcs_batch *b, bool small, const std::vector<uint3
             MALCS_HIP(malcs_h2d(st, d_packed_off.p, packed_off.data(), cntf * 8ull));
             rc = malcs_graph_launch_compact(ctx, d_out.p, d_out_off.p, d_cnt.p, d_packed_off.p, cntf, d_packed.p);
             if (rc) return rc;
+            bool runs_home = false;
             if (hook) {
                 // the runs of this chunk sit compacted in device memory: whoever wants to go on with them there (the graph
                 // kernels of malcs_gbuild.hip, which also leave them sorted) does so before they come home
                 std::vector<uint64_t> index(cntf);
                 for (uint32_t f = 0; f < cntf; f++) index[f] = pos + keep[f];
-                malcs_sweep_chunk chunk{d_packed.p, d_packed_off.p, d_cnt.p, d_work.p, cntf, fwd_work.data(), got.data(), packed_off.data(), index.data()};
+                malcs_sweep_chunk chunk{d_packed.p, d_packed_off.p, d_cnt.p, d_work.p, cntf, fwd_work.data(), got.data(), packed_off.data(), index.data(),
+                                        out_runs.data() + base, kept, &runs_home};
                 rc = hook(hook_user, chunk);
                 if (rc) return rc;
             }
-            MALCS_HIP(hipMemcpyAsync(out_runs.data() + base, d_packed.p, kept * 16ull, hipMemcpyDeviceToHost, st));   // pinned destination
+            if (!runs_home) MALCS_HIP(hipMemcpyAsync(out_runs.data() + base, d_packed.p, kept * 16ull, hipMemcpyDeviceToHost, st));   // pinned destination
             MALCS_HIP(malcs_sync(st));
             stages.lap("compaction, runs to the host");
         }

@@ -1,5 +1,6 @@
 import os, sys, time
-sys.path.insert(0, "."); sys.path.insert(0, "tests")
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
 import gen
 from algebra_amd import _native as N
 ctx = N.Context(0)
