@@ -128,7 +128,7 @@ def extra_configs(ctx, _native, gen):
             g.close()
     wall = sorted(walls)[1]
     out["c2_lcs_graphs"] = {"pairs": n, "graphs_per_s": round(n / wall, 1), "wall_ms_of_three_calls": [round(w * 1e3, 2) for w in walls],
-                            "device_path": "one-wave sweeps (k_sweep_reach + k_sweep_runs)",
+                            "device_path": "one-wave sweeps, up to 8 pairs per wave (k_sweep_reach_multi + k_sweep_runs_multi)",
                             "backward_sweep_ms": round(float(g.timing[0]), 3), "forward_sweep_ms": round(float(g.timing[1]), 3),
                             "graphs_built_on_device": int(g.device_built), "device_build_ms": round(float(g.device_build_ms), 3),
                             "host_build_ms": round(float(g.timing[2]), 1)}
