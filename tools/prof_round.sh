@@ -18,7 +18,11 @@ cd $R
 # the replays the roofline's kernel_ms comes from are on one stream there too)
 cd /tmp
 timeout -k 10 300 rocprofv3 --kernel-trace --stats -d $P/stats3 -o stats3 -- python3 $R/bench.py --no-cpu-baseline --no-extra --steps 200 --warmup 20 > $P/stats3.log 2>&1
+# C2's 100 000 graphs by the default path: one-wave sweeps with several pairs per wave, run ordering, construction
+timeout -k 10 200 rocprofv3 --kernel-trace --stats -d $P/graphs -o graphs -- python3 $R/tools/time_gbuild.py > $P/graphs.log 2>&1
 cd $R
+python3 tools/prof_summary.py ${TAG}_graphs $P/graphs > /dev/null
+sed -i "1a # command: rocprofv3 --kernel-trace --stats -- python3 tools/time_gbuild.py   (100 000 C2 pairs, Batch.graphs() three times; extra.c2_lcs_graphs of the bench)" profiles/${TAG}_graphs_bench_stats.txt
 python3 tools/prof_summary.py ${TAG}_in_flight $P/stats3 > /dev/null
 sed -i "1a # command: rocprofv3 --kernel-trace --stats -- python3 bench.py --no-cpu-baseline --no-extra --steps 200 --warmup 20   (the default: three batches in flight)" profiles/${TAG}_in_flight_bench_stats.txt
 python3 tools/prof_summary.py $TAG $P/stats $P/fetch $P/write "$B --steps 200 --warmup 20 (stats) / --steps 20 --warmup 2 (FETCH_SIZE and WRITE_SIZE, a pass each)" > /dev/null
@@ -32,7 +36,7 @@ json.dump({"command": "rocprofv3 --pmc SQ_INSTS_LDS SQ_ACTIVE_INST_LDS SQ_LDS_ID
            "kernel": "k_llcs_diag<3,2,true>", "per_launch": dict(rows)}, open(f"profiles/{tag}_lds.json", "w"), indent=1)
 PY
 sed -i "1a # command: rocprofv3 --kernel-trace --stats -- $B --steps 200 --warmup 20" profiles/${TAG}_bench_stats.txt
-cp profiles/${TAG}_in_flight_bench_stats.txt profiles/${TAG}_bench_stats.txt profiles/${TAG}_pmc.json profiles/${TAG}_valu.json profiles/${TAG}_lds.json gpurun_out/prof_$TAG/
+cp profiles/${TAG}_graphs_bench_stats.txt profiles/${TAG}_in_flight_bench_stats.txt profiles/${TAG}_bench_stats.txt profiles/${TAG}_pmc.json profiles/${TAG}_valu.json profiles/${TAG}_lds.json gpurun_out/prof_$TAG/
 grep "^{" $P/stats.log > gpurun_out/prof_$TAG/bench_line_under_stats.json || true
 rm -rf $P
 head -6 profiles/${TAG}_bench_stats.txt
