@@ -1,6 +1,6 @@
 """Dev tool: randomised differential run of the library against the oracle (distances of every pair, graphs of a sample),
 over batches of mixed shapes and the environment switches that pick other kernels.  On the GPU box:
-    python tools/fuzz_parity.py [SECONDS] [FIRST_SEED]
+    python tools/fuzz_parity.py [SECONDS] [FIRST_SEED] [long]
 Prints one line per batch; stops at the first difference (exit code 1) with the seed, the switches and the pair."""
 import os, sys, time
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -14,10 +14,15 @@ SWITCHES = [{}, {"MALCS_SWEEP_MIN_ROWS": "1", "MALCS_SWEEP_RATIO": "0"}, {"MALCS
             {"MALCS_SWEEP_MIN_ROWS": "1", "MALCS_SWEEP_RATIO": "0", "MALCS_SWEEP_PPW": "4"}]
 
 
+LONG = len(sys.argv) > 3 and sys.argv[3] == "long"        # few pairs of up to 70 000 symbols: big sweeps, band kernels, sliding windows
+
+
 def batch_of(rs):
     nsym = int(rs.choice([2, 3, 4, 4, 4, 5, 13, 20]))
     n = int(rs.choice([1, 7, 63, 64, 65, 300, 1500, 5000]))
     top = int(rs.choice([8, 70, 200, 700, 1100, 2600, 5000]))
+    if LONG:
+        nsym, n, top = 4, int(rs.choice([1, 3, 8])), int(rs.choice([5000, 20000, 70000]))
     seqs = []
     for i in range(n):
         length = int(rs.randint(0, top + 1))
@@ -33,16 +38,13 @@ def batch_of(rs):
             a = np.concatenate([a[:at], np.tile(unit, int(rs.randint(2, 12))), a[at:]])
             b = np.concatenate([a[:at], np.tile(unit, int(rs.randint(0, 14))), a[at + len(unit) * 3:]])
         else:
-            p = float(rs.choice([0.001, 0.005, 0.02, 0.05, 0.15]))
+            p = float(rs.choice([0.0002, 0.001, 0.004] if LONG else [0.001, 0.005, 0.02, 0.05, 0.15]))
             keep = rs.random_sample(length) >= p
             ins = rs.random_sample(length) < p
-            out = []
-            for j in range(length):
-                if ins[j]:
-                    out.append(rs.randint(0, nsym))
-                if keep[j]:
-                    out.append(a[j])
-            b = np.array(out, dtype=np.uint8)
+            where = np.repeat(np.arange(length), ins.astype(np.int64) + keep.astype(np.int64))      # an inserted symbol, then the kept one
+            fresh = np.ones(len(where), bool)
+            fresh[np.cumsum(ins.astype(np.int64) + keep.astype(np.int64))[keep] - 1] = False
+            b = np.where(fresh, rs.randint(0, nsym, len(where)), a[where] if length else 0).astype(np.uint8)
         if rs.randint(0, 2):
             a, b = b, a
         seqs.append((a, b))
