@@ -973,6 +973,53 @@ def test_sweeps_with_several_pairs_per_wave(native, nsym, monkeypatch):
             r.close()
 
 
+def test_graphs_from_two_host_threads_with_a_context_each(native):
+    """A context is a stream, a pool and worker threads of its own: two host threads, each with its context and batch,
+    build their graphs side by side (ctypes releases the GIL for the call; one thread's host loops run under the
+    other's kernels: 8.7 -> 6.6 ms per 100 000 C2 graphs, tools/time_graphs_in_flight.py) and get what one thread gets."""
+    import threading
+    datas = [gen.c2_batch(6000, seed=41 + t) for t in range(2)]
+    ctxs = [native.Context(0) for _ in range(2)]
+    alone = []
+    for t in range(2):
+        b = native.Batch(ctxs[t], *datas[t], 4)
+        alone.append(b.graphs())
+        b.close()
+    together = [[], []]
+    errors = []
+
+    def work(t):
+        try:
+            for _ in range(3):
+                b = native.Batch(ctxs[t], *datas[t], 4)
+                together[t].append(b.graphs())
+                b.close()
+        except Exception as e:                                # noqa: BLE001 -- reported by the assert below
+            errors.append(e)
+
+    threads = [threading.Thread(target=work, args=(t,)) for t in range(2)]
+    for th in threads:
+        th.start()
+    for th in threads:
+        th.join()
+    try:
+        assert not errors, errors
+        for t in range(2):
+            want = alone[t]
+            for got in together[t]:
+                assert got.device_built == 6000
+                assert np.array_equal(got.distance, want.distance) and np.array_equal(got.counts, want.counts)
+                assert np.array_equal(got.supremal, want.supremal)
+                for i in range(0, 6000, 7):
+                    assert np.array_equal(got.nodes(i), want.nodes(i)) and np.array_equal(got.edges(i), want.edges(i)), (t, i)
+                    assert np.array_equal(got.runs(i), want.runs(i)), (t, i)
+    finally:
+        for g in alone + together[0] + together[1]:
+            g.close()
+        for c in ctxs:
+            c.close()
+
+
 @pytest.mark.parametrize("path", ["sweep", "band"])
 def test_c5_ii_one_megabase_two_percent(native, path, monkeypatch):
     """BASELINE config 5 (ii): one 1 Mb pair at 2 % indels (D about 20 000) on both device paths.
