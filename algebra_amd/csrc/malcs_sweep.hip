@@ -880,12 +880,17 @@ int launch_runs(malcs_batch *b, bool small, uint32_t count, const uint32_t *d_wo
 
 // pairs per wave of the one-wave sweeps: as many as the widest pair of the chunk leaves room for (its diagonals in its
 // group's share of the LDS array); MALCS_SWEEP_PPW caps it (1: the one-pair kernels)
+int ppw_of_diagonals(int64_t ndiag)
+{
+    return ndiag <= SMALL_DIAGS / 8 ? 8 : ndiag <= SMALL_DIAGS / 4 ? 4 : ndiag <= SMALL_DIAGS / 2 ? 2 : 1;
+}
+
 int sweep_ppw(bool small, const std::vector<int64_t> &ndiag)
 {
     if (!small || ndiag.empty()) return 1;
     int64_t widest = 0;
     for (int64_t v : ndiag) widest = std::max(widest, v);
-    int ppw = widest <= SMALL_DIAGS / 8 ? 8 : widest <= SMALL_DIAGS / 4 ? 4 : widest <= SMALL_DIAGS / 2 ? 2 : 1;
+    int ppw = ppw_of_diagonals(widest);
     if (const char *e = getenv("MALCS_SWEEP_PPW")) ppw = std::min(ppw, atoi(e) >= 8 ? 8 : atoi(e) >= 4 ? 4 : atoi(e) >= 2 ? 2 : 1);
     return ppw;
 }
@@ -1133,6 +1138,5 @@ int malcs_sweep_small_dmax() { return SMALL_DMAX; }
 // the caller orders its list by this number, so that a few distant pairs do not take the whole batch to one pair per wave
 int malcs_sweep_pairs_per_wave(int64_t D)
 {
-    const int64_t ndiag = 2 * D + 3;
-    return ndiag <= SMALL_DIAGS / 8 ? 8 : ndiag <= SMALL_DIAGS / 4 ? 4 : ndiag <= SMALL_DIAGS / 2 ? 2 : 1;
+    return ppw_of_diagonals(2 * D + 3);
 }
