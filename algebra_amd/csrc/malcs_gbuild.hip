@@ -190,9 +190,9 @@ k_events_to_runs(const uint4 *__restrict__ events, const uint64_t *__restrict__ 
 
 int malcs_gbuild_pair_out_words() { return PAIR_OUT; }
 
-// kind 0: graphs of at most 32 runs on a small arena in LDS (7.5 KB per wave: twice as many waves per CU as kind 1, and
+// kind 0: graphs of at most 32 runs on a small arena in LDS (7 KB per wave with the sorted runs: twice as many waves per CU as kind 1, and
 // the construction is a chain of dependent LDS accesses that only other waves can hide; 99 % of the graphs of 1 kb
-// windows at 2 % indels); kind 1: at most 64 runs, LDS arena of 13.5 KB; kind 2: at most 1 024 runs on an arena in `scratch`
+// windows at 2 % indels); kind 1: at most 64 runs, 12.5 KB of LDS; kind 2: at most 1 024 runs on an arena in `scratch`
 int malcs_gbuild_launch(malcs_ctx *ctx, int kind, uint4 *d_runs, const uint64_t *d_run_off, const uint32_t *d_run_cnt,
                         const uint32_t *d_pids, const uint32_t *d_slots, uint32_t n_slots, const uint32_t *d_a_len,
                         const uint32_t *d_b_len, const int32_t *d_dist, const int64_t *d_shift, int32_t *d_scratch,
