@@ -139,9 +139,12 @@ struct pair_graph {
     const int16_t *dev_nodes16 = nullptr, *dev_edges16 = nullptr;      // ... or as int16 (graphs the device built over windows below 32 768)
     int64_t node_word(size_t i) const { return dev_nodes16 ? dev_nodes16[i] : dev_nodes[i]; }
     int64_t edge_word(size_t i) const { return dev_edges16 ? dev_edges16[i] : dev_edges[i]; }
-    const uint32_t *dev_runs = nullptr;      // its runs as the kernels left them (sorted, without the shift), 4 per run
+    // its runs as the kernels left them (sorted, without the shift), 4 per run: where they are, or (dev_runs_set >= 0) the
+    // index of the first in the flat array of that sweep set, which may still grow while later chunks come home
+    union { const uint32_t *dev_runs = nullptr; uint64_t dev_runs_at; };
     int64_t dev_n_nodes = 0, dev_n_edges = 0, dev_n_runs = 0, dev_shift = 0;
     bool dev_built = false;
+    int8_t dev_runs_set = -1;
     size_t n_nodes() const { return narrow ? (size_t)dev_n_nodes : nodes.size() / 3; }
     size_t n_edges() const { return narrow ? (size_t)dev_n_edges : edges.size() / 6; }
     size_t n_runs() const { return dev_built ? (size_t)dev_n_runs : runs.size() / 4; }
@@ -522,10 +525,11 @@ static void widen(malcs_graphs *g, pair_graph &G)
     if (!G.narrow || G.nodes.p) return;
     if (g->stores.empty()) g->stores.resize(1);
     if (G.dev_built) {
+        const uint32_t *src = G.dev_runs_set >= 0 ? g->sweeps[G.dev_runs_set].flat.data() + 4 * G.dev_runs_at : G.dev_runs;
         G.runs = g->stores[0].take((size_t)G.dev_n_runs * 4);
         for (int64_t r = 0; r < G.dev_n_runs; r++) {
-            G.runs[4 * r] = G.dev_runs[4 * r] + G.dev_shift; G.runs[4 * r + 1] = G.dev_runs[4 * r + 1] + G.dev_shift;
-            G.runs[4 * r + 2] = G.dev_runs[4 * r + 2]; G.runs[4 * r + 3] = G.dev_runs[4 * r + 3];
+            G.runs[4 * r] = src[4 * r] + G.dev_shift; G.runs[4 * r + 1] = src[4 * r + 1] + G.dev_shift;
+            G.runs[4 * r + 2] = src[4 * r + 2]; G.runs[4 * r + 3] = src[4 * r + 3];
         }
     }
     G.nodes = g->stores[0].take((size_t)G.dev_n_nodes * 3);
@@ -547,6 +551,7 @@ static void widen(malcs_graphs *g, pair_graph &G)
 struct gbuild_user {
     malcs_batch *b; malcs_graphs *out; const int64_t *shift; const int64_t *d_shift;
     const std::vector<uint32_t> *work;                                   // the work list the chunk's work_index refers to
+    int set;                                                             // the sweep set whose flat array takes the chunk's runs (-1: the caller points the handles at them)
 };
 
 static int gbuild_hook(void *user_, const malcs_sweep_chunk &c)
@@ -683,6 +688,9 @@ static int gbuild_hook(void *user_, const malcs_sweep_chunk &c)
             if (half16) { G.dev_nodes16 = reinterpret_cast<const int16_t *>(words); G.dev_edges16 = G.dev_nodes16 + 3 * n_nodes; }
             else { G.dev_nodes = words; G.dev_edges = words + 3 * n_nodes; }
             G.dev_n_nodes = (int64_t)n_nodes; G.dev_n_edges = (int64_t)n_edges; G.dev_shift = sh;
+            G.dev_n_runs = (int64_t)c.cnt[f];
+            G.n_levels = ((int64_t)u.b->a_len[c.pids[f]] + (int64_t)u.b->b_len[c.pids[f]] - G.distance) / 2;
+            if (u.set >= 0) { G.dev_runs_set = (int8_t)u.set; G.dev_runs_at = c.runs_base + c.run_off[f]; }
             G.supremal[0] = po[3] + sh; G.supremal[1] = po[4] + sh; G.supremal[2] = po[5]; G.supremal[3] = po[6];
             G.dev_built = true;
             G.narrow = true;
@@ -854,7 +862,7 @@ static int graph_batch(malcs_batch *b, const int64_t *shift, const int64_t *max_
         sweep_set &S = sweeps[shape];
         if (S.pairs.empty()) continue;
         float ms[2] = {0, 0};
-        gbuild_user user{b, out, shift, d_shift.p, &S.pairs};
+        gbuild_user user{b, out, shift, d_shift.p, &S.pairs, shape};
         int rc = malcs_sweep_optimal_runs(b, shape == 1, S.pairs, dist.data(), 0, S.flat, S.first, ms, on_device ? gbuild_hook : nullptr, &user);
         if (rc) return rc;
         ms_fwd += ms[0]; ms_reach += ms[1];
@@ -1009,14 +1017,14 @@ static int graph_batch(malcs_batch *b, const int64_t *shift, const int64_t *max_
                                                                   d_runs.p, d_runoff.p, d_runcnt.p);
                         if (rc) return rc;
                         MALCS_HIP(malcs_sync(st));                               // (`slots` and `run_off` are locals the copies read)
-                        gbuild_user user{b, out, shift, d_shift.p, nullptr};
+                        gbuild_user user{b, out, shift, d_shift.p, nullptr, -1};
                         // the runs, sorted by the graph kernels, for the handle (runs(i)) of the pairs that were built there
                         bv_runs.emplace_back();
                         pinned_vec<uint32_t> &flat = bv_runs.back();
                         flat.resize((size_t)runs_total * 4);
                         bool runs_home = false;
                         const malcs_sweep_chunk chunk{d_runs.p, d_runoff.p, d_runcnt.p, d_work.p, cnt, work.data(), run_cnt.data(), run_off.data(), nullptr,
-                                                      flat.data(), runs_total, &runs_home};
+                                                      flat.data(), runs_total, &runs_home, 0};
                         rc = gbuild_hook(&user, chunk);
                         if (rc) return rc;
                         if (!runs_home) MALCS_HIP(hipMemcpyAsync(flat.data(), d_runs.p, runs_total * 16ull, hipMemcpyDeviceToHost, st));
@@ -1076,16 +1084,7 @@ static int graph_batch(malcs_batch *b, const int64_t *shift, const int64_t *max_
             pair_graph &G = out->g[i];
             if (G.status != MALCS_PAIR_OK) continue;
             const int64_t m = b->a_len[i], n = b->b_len[i];
-            if (G.dev_built) {                                           // all done on the device: point at what came home
-                if (has_runs[i] >= 2) {                                  // (the bit-vector chunks have set theirs)
-                    const sweep_set &S = sweeps[has_runs[i] - 2];
-                    const uint64_t s = sweep_slot[i];
-                    G.dev_runs = S.flat.data() + 4 * S.first[s];
-                    G.dev_n_runs = (int64_t)(S.first[s + 1] - S.first[s]);
-                }
-                G.n_levels = (m + n - G.distance) / 2;
-                continue;
-            }
+            if (G.dev_built) continue;                                   // all done on the device, the handle points at what came home (gbuild_hook)
             runs.clear();
             const double ta = trace ? now_ms() : 0;
             if (has_runs[i] >= 2) {                                      // runs straight from the sweep kernels
@@ -1127,7 +1126,8 @@ static int graph_batch(malcs_batch *b, const int64_t *shift, const int64_t *max_
     out->stores.resize(nt);
     out->narrow.resize(nt);
     jobs.builders.store((int)nt);
-    if (wk && nt > 1) wk->run((int)nt, [&](int k) { worker(&out->stores[(size_t)k], &out->narrow[(size_t)k]); });
+    if (out->n_dev_built == N) jobs.builders.store(0);                   // every pair's graph came from the device: no pass over the handles
+    else if (wk && nt > 1) wk->run((int)nt, [&](int k) { worker(&out->stores[(size_t)k], &out->narrow[(size_t)k]); });
     else worker(&out->stores[0], &out->narrow[0]);
     out->timing[2] = (float)(now_ms() - t0);
     stages.lap("host build");

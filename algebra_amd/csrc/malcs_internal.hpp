@@ -270,6 +270,7 @@ struct malcs_sweep_chunk {
     uint32_t count;
     const uint32_t *pids, *cnt; const uint64_t *run_off, *work_index;      // host copies
     uint32_t *host_runs; uint64_t n_runs; bool *runs_home;
+    uint64_t runs_base;                                                    // runs of earlier chunks in the caller's array (host_runs begins behind them)
 };
 typedef int (*malcs_sweep_hook)(void *user, const malcs_sweep_chunk &chunk);
 int malcs_sweep_distances(malcs_batch *b, const std::vector<uint32_t> &pairs, int32_t cap, std::vector<int32_t> &out);

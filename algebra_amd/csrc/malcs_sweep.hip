@@ -1111,7 +1111,7 @@ int malcs_sweep_optimal_runs(malcs_batch *b, bool small, const std::vector<uint3
                 std::vector<uint64_t> index(cntf);
                 for (uint32_t f = 0; f < cntf; f++) index[f] = pos + keep[f];
                 malcs_sweep_chunk chunk{d_packed.p, d_packed_off.p, d_cnt.p, d_work.p, cntf, fwd_work.data(), got.data(), packed_off.data(), index.data(),
-                                        out_runs.data() + base, kept, &runs_home};
+                                        out_runs.data() + base, kept, &runs_home, (uint64_t)(base >> 2)};
                 rc = hook(hook_user, chunk);
                 if (rc) return rc;
             }
