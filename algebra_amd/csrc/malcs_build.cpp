@@ -122,29 +122,32 @@ struct i32_store {
 };
 
 struct pair_graph {
+    // first what every pass over the handles of a batch touches (112 bytes: a batch of 100 000 is a 20 MB array, and the
+    // passes -- launch classes, the device's graphs pointed at, the columns a caller reads -- cost what they miss in cache)
     int32_t status = MALCS_PAIR_OK;
+    // narrow: the graph's arrays as int32 / int16 words, coordinates without the shift (what malcs_graph_core.hpp writes,
+    // on the host or on the device: dev_built, malcs_gbuild.hip); `nodes` / `edges` below are filled from them when somebody
+    // needs the int64 arrays in place (widen()), the copy-out entry points widen on the way
+    bool narrow = false, dev_built = false, canon_done = false;
+    uint8_t dev_runs_in = 0;        // 0: dev_runs is an address; k + 1: an index into the flat array of sweep set k (see below)
     int64_t distance = 0;
     int64_t n_levels = 0;
     int64_t supremal[4] = {0, 0, 0, 0};
+    int64_t dev_n_nodes = 0, dev_n_edges = 0, dev_n_runs = 0, dev_shift = 0;
+    const int16_t *dev_nodes16 = nullptr, *dev_edges16 = nullptr;      // the words as int16 (graphs the device built over windows below 32 768)
+    // its runs as the kernels left them (sorted, without the shift), 4 per run: where they are, or (dev_runs_in > 0) the
+    // index of the first in the flat array of that sweep set, which may still grow while later chunks come home.
+    // (Every member starts as zero: a batch's array of handles is made by clearing it, 0.3 ms per 100 000; one member
+    // that started as -1 made that 1.6 ms.)
+    union { const uint32_t *dev_runs = nullptr; uint64_t dev_runs_at; };
+    // ... then what a reader of one graph needs
+    const int32_t *dev_nodes = nullptr, *dev_edges = nullptr;          // the words as int32
     i64_view runs;                  // 4 per run (shifted row, col; length; level)
     i64_view nodes;                 // 3 per node
     i64_view edges;                 // 6 per edge
     std::vector<int64_t> canon;     // 4 per canonical variant (start, end, obs_from, obs_to), filled on demand
-    bool canon_done = false;
-    // narrow: the graph's arrays as int32 words, coordinates without the shift (what malcs_graph_core.hpp writes, on the
-    // host or on the device: dev_built, malcs_gbuild.hip); `nodes` / `edges` above are filled from them when somebody
-    // needs the int64 arrays in place (widen()), the copy-out entry points widen on the way
-    bool narrow = false;
-    const int32_t *dev_nodes = nullptr, *dev_edges = nullptr;
-    const int16_t *dev_nodes16 = nullptr, *dev_edges16 = nullptr;      // ... or as int16 (graphs the device built over windows below 32 768)
     int64_t node_word(size_t i) const { return dev_nodes16 ? dev_nodes16[i] : dev_nodes[i]; }
     int64_t edge_word(size_t i) const { return dev_edges16 ? dev_edges16[i] : dev_edges[i]; }
-    // its runs as the kernels left them (sorted, without the shift), 4 per run: where they are, or (dev_runs_set >= 0) the
-    // index of the first in the flat array of that sweep set, which may still grow while later chunks come home
-    union { const uint32_t *dev_runs = nullptr; uint64_t dev_runs_at; };
-    int64_t dev_n_nodes = 0, dev_n_edges = 0, dev_n_runs = 0, dev_shift = 0;
-    bool dev_built = false;
-    int8_t dev_runs_set = -1;
     size_t n_nodes() const { return narrow ? (size_t)dev_n_nodes : nodes.size() / 3; }
     size_t n_edges() const { return narrow ? (size_t)dev_n_edges : edges.size() / 6; }
     size_t n_runs() const { return dev_built ? (size_t)dev_n_runs : runs.size() / 4; }
@@ -525,7 +528,7 @@ static void widen(malcs_graphs *g, pair_graph &G)
     if (!G.narrow || G.nodes.p) return;
     if (g->stores.empty()) g->stores.resize(1);
     if (G.dev_built) {
-        const uint32_t *src = G.dev_runs_set >= 0 ? g->sweeps[G.dev_runs_set].flat.data() + 4 * G.dev_runs_at : G.dev_runs;
+        const uint32_t *src = G.dev_runs_in ? g->sweeps[G.dev_runs_in - 1].flat.data() + 4 * G.dev_runs_at : G.dev_runs;
         G.runs = g->stores[0].take((size_t)G.dev_n_runs * 4);
         for (int64_t r = 0; r < G.dev_n_runs; r++) {
             G.runs[4 * r] = src[4 * r] + G.dev_shift; G.runs[4 * r + 1] = src[4 * r + 1] + G.dev_shift;
@@ -668,7 +671,7 @@ static int gbuild_hook(void *user_, const malcs_sweep_chunk &c)
     stages.lap("kernels, counts home");
     MALCS_HIP(hipStreamSynchronize(ctx->copy_stream));
     stages.lap("graphs home");
-    // the handles of the pairs that were built point at what came home: a loop over the pairs whose cost is the 216 bytes
+    // the handles of the pairs that were built point at what came home: a loop over the pairs whose cost is the cache lines
     // of handle it touches per pair (0.4 ms for 100 000 on one thread), so the context's threads share large chunks
     std::atomic<uint64_t> built(0);
     auto point_at = [&](size_t k, size_t q_lo, size_t q_hi) {
@@ -690,7 +693,7 @@ static int gbuild_hook(void *user_, const malcs_sweep_chunk &c)
             G.dev_n_nodes = (int64_t)n_nodes; G.dev_n_edges = (int64_t)n_edges; G.dev_shift = sh;
             G.dev_n_runs = (int64_t)c.cnt[f];
             G.n_levels = ((int64_t)u.b->a_len[c.pids[f]] + (int64_t)u.b->b_len[c.pids[f]] - G.distance) / 2;
-            if (u.set >= 0) { G.dev_runs_set = (int8_t)u.set; G.dev_runs_at = c.runs_base + c.run_off[f]; }
+            if (u.set >= 0) { G.dev_runs_in = (uint8_t)(u.set + 1); G.dev_runs_at = c.runs_base + c.run_off[f]; }
             G.supremal[0] = po[3] + sh; G.supremal[1] = po[4] + sh; G.supremal[2] = po[5]; G.supremal[3] = po[6];
             G.dev_built = true;
             G.narrow = true;
@@ -732,11 +735,14 @@ static int graph_batch(malcs_batch *b, const int64_t *shift, const int64_t *max_
 
     // exact distances first (kernel family 1): they decide max_distance, the band and the event budget
     std::vector<int32_t> dist(N, -1);
+    stages.lap("handles and lists made");
     if (N) {
         int rc = malcs_dist_launch_resident(b);
         if (rc) return rc;
+        stages.lap("distance kernels queued");
         MALCS_HIP(malcs_d2h(st, dist.data(), b->d_dist, N * 4ull));
         MALCS_HIP(malcs_sync(st));
+        stages.lap("distances home");
         // Sequences beyond a resident pattern: the backward sweep finds the distance while it fills its table, first
         // with room for 1 024 edits, then for sweep_dmax; what is further apart goes to the band kernels.
         std::vector<uint32_t> todo;
