@@ -1000,7 +1000,7 @@ int malcs_sweep_optimal_runs(malcs_batch *b, bool small, const std::vector<uint3
         MALCS_HIP(malcs_h2d(st, d_work.p, work.data() + pos, cnt * 4ull));
         MALCS_HIP(malcs_h2d(st, d_dists.p, dists.data(), cnt * 4ull));
         MALCS_HIP(malcs_h2d(st, d_tab_off.p, tab_off.data(), cnt * 8ull));
-        MALCS_HIP(malcs_h2d(st, d_fr_off.p, fr_off_b.data(), cnt * 8ull));
+        if (fr_b) MALCS_HIP(malcs_h2d(st, d_fr_off.p, fr_off_b.data(), cnt * 8ull));   // (read only by pairs whose diagonals do not fit LDS)
         // an entry never written reaches nothing (with a cap instead of the distance the table may be GBs, and every
         // entry the forward pass looks up has been written: skip the fill)
         if (!unknown_cap) MALCS_HIP(hipMemsetAsync(d_tab.p, 0xff, tab_total * 4ull, st));
@@ -1022,6 +1022,7 @@ int malcs_sweep_optimal_runs(malcs_batch *b, bool small, const std::vector<uint3
         std::vector<uint64_t> fwd_tab_off;
         std::vector<int32_t> fwd_dists;
         uint32_t cntf;
+        uint64_t fr_fwd = fr_f;                                               // words of scratch the forward pass's diagonals need beyond LDS
         if (!unknown_cap) {
             // the distances were known: every pair goes on, and its number, distance, table offset and the forward
             // pass's layout (worked out above) are what the device already holds or the host already has
@@ -1050,6 +1051,7 @@ int malcs_sweep_optimal_runs(malcs_batch *b, bool small, const std::vector<uint3
             for (uint32_t f = 0; f < cntf; f++) fwd_dists[f] = found[keep[f]];
             const uint64_t fr_f2 = fr_layout(nd_fwd, lds_diags, fr_off_f);
             if (fr_f2 > std::max(fr_b, fr_f)) { malcs_set_error("sweep scratch too small (internal error)"); return MALCS_ERR_INTERNAL; }
+            fr_fwd = fr_f2;
             MALCS_HIP(malcs_h2d(st, d_work.p, fwd_work.data(), cntf * 4ull));
             MALCS_HIP(malcs_h2d(st, d_dists.p, fwd_dists.data(), cntf * 4ull));
             MALCS_HIP(malcs_h2d(st, d_tab_off.p, fwd_tab_off.data(), cntf * 8ull));
@@ -1061,7 +1063,7 @@ int malcs_sweep_optimal_runs(malcs_batch *b, bool small, const std::vector<uint3
             cap[f] = 64u + 16u * (uint32_t)fwd_dists[f];
             off[f] = total; total += cap[f];
         }
-        MALCS_HIP(malcs_h2d(st, d_fr_off.p, fr_off_f.data(), cntf * 8ull));
+        if (fr_fwd) MALCS_HIP(malcs_h2d(st, d_fr_off.p, fr_off_f.data(), cntf * 8ull));
         const int ppw_f = sweep_ppw(small, nd_fwd);
         for (int attempt = 0;; attempt++) {
             d_out.release();
