@@ -779,6 +779,13 @@ static int graph_batch(malcs_batch *b, const int64_t *shift, const int64_t *max_
         }
     }
 
+    {   // the distances into the handles: by the context's threads when the batch is large
+        auto put = [&](uint64_t lo, uint64_t hi) { for (uint64_t i = lo; i < hi; i++) out->g[i].distance = dist[i]; };
+        malcs_workers *wk = N >= 16384 ? malcs_ctx_workers(ctx) : nullptr;
+        const int nt = wk ? (int)std::min<size_t>(16, wk->size()) : 1;
+        if (nt > 1) wk->run(nt, [&](int t) { put(N * (uint64_t)t / (uint64_t)nt, N * (uint64_t)(t + 1) / (uint64_t)nt); });
+        else put(0, N);
+    }
     stages.lap("distances");
     // launch classes.  Short windows keep all their row groups resident (L lanes per pair, several pairs per
     // wave); longer ones get a wave each whose 64 lanes slide along the band given by the distance.
@@ -792,28 +799,27 @@ static int graph_batch(malcs_batch *b, const int64_t *shift, const int64_t *max_
     if (const char *e = getenv("MALCS_SWEEP_RATIO")) small_ratio = atoll(e);
     for (uint64_t i = 0; i < N; i++) {
         const uint32_t m = b->a_len[i], n = b->b_len[i];
-        pair_graph &G = out->g[i];
-        G.distance = dist[i];
+        const int64_t D = dist[i];                    // (the loop reads lengths and distances only: a handle is 200 bytes away from the next)
         const int64_t md = max_distance ? max_distance[i] : 0;
-        if (md && G.distance > md) { G.status = MALCS_PAIR_MAX_DISTANCE_EXCEEDED; continue; }
+        if (md && D > md) { out->g[i].status = MALCS_PAIR_MAX_DISTANCE_EXCEEDED; continue; }
         if (m == 0 || n == 0) continue;               // no DP needed: LLCS = 0
         if (has_runs[i] >= 4) continue;               // its runs came with its distance
         int W = 0, logL = 0;
         bool band = false;
-        if (m >= 4096u && G.distance <= sweep_dmax) {  // long and similar: the output-sensitive sweeps (malcs_sweep.hip)
+        if (m >= 4096u && D <= sweep_dmax) {  // long and similar: the output-sensitive sweeps (malcs_sweep.hip)
             sweeps[0].pairs.push_back((uint32_t)i);
             has_runs[i] = 2;
             continue;
         }
-        if (m < 4096u && (int64_t)m >= small_rows && G.distance <= std::min<int64_t>(sweep_dmax, malcs_sweep_small_dmax()) &&
-            small_ratio * G.distance <= (int64_t)std::max(m, n)) {   // similar windows: D + 1 steps of a wave instead of n columns
+        if (m < 4096u && (int64_t)m >= small_rows && D <= std::min<int64_t>(sweep_dmax, malcs_sweep_small_dmax()) &&
+            small_ratio * D <= (int64_t)std::max(m, n)) {   // similar windows: D + 1 steps of a wave instead of n columns
             sweeps[1].pairs.push_back((uint32_t)i);
             has_runs[i] = 3;
             continue;
         }
         if (m < 4096u) {
             const uint32_t words = m / 64u + 1u;
-            if (resident_band && words >= 4 && 4 * (G.distance + 2) <= (int64_t)m) {
+            if (resident_band && words >= 4 && 4 * (D + 2) <= (int64_t)m) {
                 // all groups resident, but only the band's tie bits stored (the distance is known: the band kernels' bounds):
                 // groups of 64 rows, so that the two or three groups a column's band touches are a fraction of the window
                 W = 1;
@@ -824,7 +830,7 @@ static int graph_batch(malcs_batch *b, const int64_t *shift, const int64_t *max_
         } else {
             band = true;
             logL = 6;
-            for (W = 1; W <= band_wmax && band_capacity(W) < G.distance + 2; W *= 2) {}
+            for (W = 1; W <= band_wmax && band_capacity(W) < D + 2; W *= 2) {}
             if (W > band_wmax) {
                 if (m < 16384u) {                       // too divergent for a band: all groups resident
                     band = false; W = 4; logL = 0;
@@ -832,7 +838,7 @@ static int graph_batch(malcs_batch *b, const int64_t *shift, const int64_t *max_
                     while ((1u << logL) < lanes) logL++;
                 } else {
                     malcs_set_error("pair %llu: windows of %u and %u symbols at distance %lld exceed the widest band "
-                                    "(%d edits) the graph kernels hold", (unsigned long long)i, m, n, (long long)G.distance,
+                                    "(%d edits) the graph kernels hold", (unsigned long long)i, m, n, (long long)D,
                                     band_capacity(band_wmax) - 2);
                     return MALCS_ERR_TOO_LONG;
                 }
