@@ -130,7 +130,7 @@ k_lcs_sweep(const uint32_t *__restrict__ planes, const uint32_t *__restrict__ a_
 // ---- output-sensitive path for long, similar pairs ---------------------------------------------------------
 // The bit-vector kernels of malcs_graph.hip cost (columns x band) whatever the sequences hold; a pair of 1 Mb
 // windows a few dozen edits apart is one wave crawling along a million columns.  The furthest-reaching recurrence
-// costs O(n / 32 + D^2): slides compare 32 cells per step, and a slide that does not end within two words is
+// costs O(n / 32 + D^2): slides compare 32 cells per step, and a slide that does not end within a lane's two (one-wave kernels: eight) words is
 // finished by the whole workgroup (every thread one word, first mismatch by an LDS minimum).
 //
 //   k_sweep_reach<NP, REV>   FR_d[k] for d = 0, 1, ... until the corner is reached (=> the distance, without
@@ -145,7 +145,11 @@ k_lcs_sweep(const uint32_t *__restrict__ planes, const uint32_t *__restrict__ a_
 // Two shapes of workgroup: long or divergent pairs get 512 threads and 8 192 diagonals in LDS, windows below 4 096
 // rows at distance <= SMALL_DMAX one wave and 1 024 diagonals -- 5 KB of LDS, so that dozens of pairs share a CU.
 constexpr int BIG_THREADS = 512, BIG_DIAGS = 8192, SMALL_THREADS = 64, SMALL_DIAGS = 1024, SMALL_DMAX = 510;
-constexpr int LOCAL_WORDS = 2;
+// words (of 32 cells) a lane slides alone before the slide goes to the queue that the whole workgroup finishes: two for
+// the workgroups of 512 (a long window's slides are thousands of cells), eight for the one-wave kernels, where a queued
+// slide stops every pair of the wave and 1 kb windows at 2 % slide 50 cells on average between edits (C2's sweeps with
+// 2 / 4 / 8 words: 0.47 + 0.47, 0.39 + 0.40, 0.37 + 0.39 ms per 100 000)
+constexpr int LOCAL_WORDS = 2, SMALL_LOCAL_WORDS = 8;
 constexpr int SWEEP_UNROLL = 4;
 constexpr int32_t NO_STOP = 0x7fffffff;
 
@@ -239,6 +243,7 @@ k_sweep_reach(const uint32_t *__restrict__ planes, const uint32_t *__restrict__ 
     __shared__ int32_t lds_fr[DG];
     __shared__ sweep_queue<TH> q;
     constexpr int U = TH >= 256 ? SWEEP_UNROLL : 1;      // a single wave rarely has more diagonals than lanes
+    constexpr int LW = TH >= 256 ? LOCAL_WORDS : SMALL_LOCAL_WORDS;
     const uint32_t w = blockIdx.x, pid = work[w];
     const int32_t m = (int32_t)a_len[pid], n = (int32_t)b_len[pid], delta = n - m, cap = caps[w];
     const uint32_t *A = planes + a_off[pid], *B = planes + b_off[pid];
@@ -294,7 +299,7 @@ k_sweep_reach(const uint32_t *__restrict__ planes, const uint32_t *__restrict__ 
                     if (valid < 32) mm |= valid <= 0 ? ~0u : (~0u << valid);
                     if (mm) { st = p + (int32_t)__builtin_ctz(mm); break; }
                     p += 32;
-                    if (wi + 1 == LOCAL_WORDS) break;
+                    if (wi + 1 == LW) break;
                     mm = cells32<NP, REV>(A, na, m, B, nb, n, p, p + k);
                 }
                 stop[u] = st;
@@ -334,6 +339,7 @@ k_sweep_runs(const uint32_t *__restrict__ planes, const uint32_t *__restrict__ a
     __shared__ int32_t lds_fr[DG];
     __shared__ sweep_queue<TH> q;
     constexpr int U = TH >= 256 ? SWEEP_UNROLL : 1;      // a single wave rarely has more diagonals than lanes
+    constexpr int LW = TH >= 256 ? LOCAL_WORDS : SMALL_LOCAL_WORDS;
     __shared__ uint32_t lds_cnt;
     const uint32_t w = blockIdx.x, pid = work[w];
     const int32_t m = (int32_t)a_len[pid], n = (int32_t)b_len[pid], delta = n - m, D = dists[w];
@@ -394,7 +400,7 @@ k_sweep_runs(const uint32_t *__restrict__ planes, const uint32_t *__restrict__ a
                     if (valid < 32) mism |= valid <= 0 ? ~0u : (~0u << valid);
                     if (mism) { st = pos + (int32_t)__builtin_ctz(mism); break; }
                     pos += 32;
-                    if (wi + 1 == LOCAL_WORDS) break;
+                    if (wi + 1 == LW) break;
                     mism = cells32<NP, false>(A, na, m, B, nb, n, pos, pos + k);
                 }
                 stop[u] = st;
@@ -461,7 +467,7 @@ k_sweep_runs(const uint32_t *__restrict__ planes, const uint32_t *__restrict__ a
 // issue, not by memory.  Here a wave is PPW groups of 64 / PPW lanes and a group does what the wave did above, for a pair
 // of its own: own diagonals (its share of the LDS array: the host sends a chunk here only if every pair's diagonals fit
 // it), own budget loop (the wave goes on until its last group is done), own counters.  What stays the wave's: the queue
-// of slides that outlast a lane's two words -- all 64 lanes finish them one after the other, with the parameters of the
+// of slides that outlast a lane's eight words -- all 64 lanes finish them one after the other, with the parameters of the
 // pair the slide belongs to.  The arithmetic is that of k_sweep_reach / k_sweep_runs, statement by statement.
 template <int NP, bool REV>
 __device__ __forceinline__ void finish_slides_multi(sweep_queue<SMALL_THREADS> &q, const int32_t *q_lane, const uint32_t *A, uint32_t na, int32_t m,
@@ -555,7 +561,7 @@ k_sweep_reach_multi(const uint32_t *__restrict__ planes, const uint32_t *__restr
                     if (left < 32) mm |= left <= 0 ? ~0u : (~0u << left);
                     if (mm) { st = p + (int32_t)__builtin_ctz(mm); break; }
                     p += 32;
-                    if (wi + 1 == LOCAL_WORDS) break;
+                    if (wi + 1 == SMALL_LOCAL_WORDS) break;
                     mm = cells32<NP, REV>(A, na, m, B, nb, n, p, p + k);
                 }
                 stop = st;
@@ -645,7 +651,7 @@ k_sweep_runs_multi(const uint32_t *__restrict__ planes, const uint32_t *__restri
                     if (left < 32) mism |= left <= 0 ? ~0u : (~0u << left);
                     if (mism) { st = pos + (int32_t)__builtin_ctz(mism); break; }
                     pos += 32;
-                    if (wi + 1 == LOCAL_WORDS) break;
+                    if (wi + 1 == SMALL_LOCAL_WORDS) break;
                     mism = cells32<NP, false>(A, na, m, B, nb, n, pos, pos + k);
                 }
                 stop = st;
