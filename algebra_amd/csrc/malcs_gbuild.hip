@@ -17,8 +17,9 @@
 //     by lane 0 on an arena in LDS (graphs of <= 64 runs; everything is a few dependent LDS accesses per step) or in a
 //     per-pair stretch of global scratch (up to 1 024 runs).  The construction is a chain of dependent list operations:
 //     its parallelism is across the pairs of a batch (thousands of waves in flight), not inside a pair;
-//   * output: lane 0 reserves the graph's words with one atomic add on a batch-wide cursor and writes nodes and edges
-//     there, so the host copies exactly what was produced.
+//   * output: lane 0 reserves the graph's words with one atomic add on a batch-wide cursor, so the host copies exactly
+//     what was produced.  A small graph (LDS arena, out-degrees that add up to at most SE edges) is numbered and written
+//     into LDS in one walk and copied out by the whole wave; a larger one is counted first and written by lane 0.
 // A pair that does not fit (too many runs, arena overflow, output buffer full) is flagged and goes through the host
 // half (malcs_build.cpp), which gives the same result.
 #include "malcs_internal.hpp"
@@ -90,9 +91,14 @@ k_graph_build(const uint4 *__restrict__ runs, const uint64_t *__restrict__ run_o
               int32_t *__restrict__ out_words, unsigned long long out_cap, unsigned long long *__restrict__ out_cursor,
               int32_t *__restrict__ pair_out)
 {
+    // SE: edges of a graph that is written into LDS first (`stage`: nodes, then edges, int16) and copied out by the whole
+    // wave; a graph with more goes the other way (counted, then written straight to memory by lane 0)
+    constexpr int SE = LDS_ARENA ? (EC * 3) / 5 : 1;
     __shared__ int32_t sorted[4 * RCAP];
     __shared__ int32_t arena_mem[LDS_ARENA ? (9 * NC + 6 * EC + 2 * LC) : 1];
+    __shared__ int16_t stage[LDS_ARENA ? 3 * NC + 6 * SE : 2];
     __shared__ int32_t bcast[4];
+    __shared__ unsigned long long bcast_at;
     if (blockIdx.x >= n_slots) return;
     const uint32_t slot = slots[blockIdx.x], lane = threadIdx.x;
     const uint32_t R = run_cnt[slot], pid = pids[slot];
@@ -106,17 +112,41 @@ k_graph_build(const uint4 *__restrict__ runs, const uint64_t *__restrict__ run_o
         sorted[4 * i] = (int32_t)u.x; sorted[4 * i + 1] = (int32_t)u.y; sorted[4 * i + 2] = (int32_t)u.z; sorted[4 * i + 3] = (int32_t)u.w;
     }
     __syncthreads();
+    malcs_core::arena A;                                                   // (every lane has the addresses, lane 0 the graph)
+    if (LDS_ARENA) malcs_core::arena_bind(A, arena_mem, NC, EC, LC);
+    else malcs_core::arena_bind(A, scratch + scratch_off[slot], 2 * (int32_t)R + 16, 8 * (int32_t)R + 64, (int32_t)R + 8);
+    int32_t source = 0, sink = 0, sup[4] = {0, 0, 0, 0}, status = 0, count = 0, R16 = 0;
+    int64_t n_edges = 0;
+    unsigned long long at = 0;
     if (lane == 0) {
-        malcs_core::arena A;
-        if (LDS_ARENA) malcs_core::arena_bind(A, arena_mem, NC, EC, LC);
-        else malcs_core::arena_bind(A, scratch + scratch_off[slot], 2 * (int32_t)R + 16, 8 * (int32_t)R + 64, (int32_t)R + 8);
         const int32_t n_levels = (m + n - dist[pid]) / 2;
-        int32_t source = 0, sink = 0, sup[4] = {0, 0, 0, 0};
         malcs_core::build(A, m, n, shift ? shift[pid] : 0, sorted, (int32_t)R, n_levels, source, sink, sup, malcs_core::no_growth());
-        int32_t status = A.overflow ? 1 : 0, count = 0, R16 = 0;
-        int64_t n_edges = 0;
-        unsigned long long at = 0;
-        if (!status) {
+        status = A.overflow ? 1 : 0;
+        bcast[0] = status; bcast[1] = A.n_nodes;
+    }
+    bool staged = false;
+    if constexpr (LDS_ARENA) {
+        // Small graphs leave through LDS: the wave clears the numbering and adds up the out-degrees (an upper bound of the
+        // edges the source reaches), lane 0 numbers and writes the graph into `stage` in one walk (no counting walk before
+        // it), reserves its words, and the wave copies them out side by side.
+        __syncthreads();
+        const int32_t nn = bcast[0] ? 0 : bcast[1];
+        int32_t degsum = 0;
+        for (int32_t v = (int32_t)lane; v < nn; v += 64) { A.id[v] = -1; degsum += A.deg[v]; }
+        for (int off = 32; off; off >>= 1) degsum += __shfl_xor(degsum, off, 64);
+        staged = !bcast[0] && degsum <= SE && m < 32768 && n < 32768;
+        __syncthreads();
+    }
+    if (lane == 0 && !status) {
+        if (staged) {
+            malcs_core::write_graph<int16_t>(A, source, stage, stage + 3 * NC, 0, nullptr, &count, &n_edges);
+            const unsigned long long items = 3ull * (unsigned)count + 6ull * (unsigned long long)n_edges;
+            const unsigned long long words = (items + 1ull) / 2ull;
+            at = atomicAdd(out_cursor, words);
+            if (at + words > out_cap) status = 1;                          // the output buffer is full: the host half takes the pair
+            R16 = 1 << 30;
+            bcast[2] = status ? -1 : count; bcast[3] = (int32_t)n_edges; bcast_at = at;
+        } else {
             count = malcs_core::count_reachable(A, source, n_edges);
             // windows below 32 768 symbols: node triples and edge tuples as int16 (half the words to bring home -- 104 MB for
             // 100 000 C2 graphs otherwise); the cursor counts int32 words either way
@@ -126,7 +156,7 @@ k_graph_build(const uint4 *__restrict__ runs, const uint64_t *__restrict__ run_o
             if (n_edges > 0x7fffffffll) status = 1;
             else {
                 at = atomicAdd(out_cursor, words);
-                if (at + words > out_cap) status = 1;                      // the output buffer is full: the host half takes the pair
+                if (at + words > out_cap) status = 1;
                 else if (half16) {
                     int16_t *o = reinterpret_cast<int16_t *>(out_words + at);
                     malcs_core::write_graph<int16_t>(A, source, o, o + 3ull * (unsigned)count, 0);
@@ -134,10 +164,20 @@ k_graph_build(const uint4 *__restrict__ runs, const uint64_t *__restrict__ run_o
                 if (half16) R16 = 1 << 30;
             }
         }
+    }
+    if constexpr (LDS_ARENA) {
+        __syncthreads();
+        if (staged && bcast[2] >= 0) {
+            const int32_t cnt = bcast[2], ne = bcast[3];
+            int16_t *o = reinterpret_cast<int16_t *>(out_words + bcast_at);
+            for (int32_t i = (int32_t)lane; i < 3 * cnt; i += 64) o[i] = stage[i];
+            for (int32_t i = (int32_t)lane; i < 6 * ne; i += 64) o[3 * cnt + i] = stage[3 * NC + i];
+        }
+    }
+    if (lane == 0) {
         po[0] = status; po[1] = count; po[2] = (int32_t)n_edges; po[3] = sup[0]; po[4] = sup[1]; po[5] = sup[2]; po[6] = sup[3];
         po[7] = (int32_t)(uint32_t)at; po[8] = (int32_t)(uint32_t)(at >> 32); po[9] = (int32_t)R | R16;        // bit 30: int16 words
     }
-    (void)bcast;
 }
 
 // ---- the bit-vector kernels' events -> runs ---------------------------------------------------------------------

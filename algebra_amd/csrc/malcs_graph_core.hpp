@@ -249,7 +249,8 @@ MALCS_HD int32_t count_reachable(arena &A, int32_t source, int64_t &n_edges)
 // node's edges up to it (children numbered already, only the source differs) instead of walking on: every entry is
 // walked once, the rest is a block copy -- a tandem-repeat graph's 600 000 edges are 50 000 entries.
 template <typename T>
-MALCS_HD void write_graph(arena &A, int32_t source, T *nodes, T *edges, int64_t shift, int32_t *where = nullptr)
+MALCS_HD void write_graph(arena &A, int32_t source, T *nodes, T *edges, int64_t shift, int32_t *where = nullptr,
+                          int32_t *n_nodes_out = nullptr, int64_t *n_edges_out = nullptr)
 {
     if (where) for (int32_t i = 0; i < A.n_edges; i++) where[i] = -1;
     int32_t seen = 0;
@@ -306,6 +307,8 @@ MALCS_HD void write_graph(arena &A, int32_t source, T *nodes, T *edges, int64_t 
         }
         ei += d;
     }
+    if (n_nodes_out) *n_nodes_out = seen;                    // (a caller that has not counted beforehand: it needs A.id = -1 for every node)
+    if (n_edges_out) *n_edges_out = ei;
 }
 
 // write_graph in two parts, for graphs large enough to share the copying among threads (host only; same arrays).
