@@ -115,12 +115,22 @@ k_graph_build(const uint4 *__restrict__ runs, const uint64_t *__restrict__ run_o
     malcs_core::arena A;                                                   // (every lane has the addresses, lane 0 the graph)
     if (LDS_ARENA) malcs_core::arena_bind(A, arena_mem, NC, EC, LC);
     else malcs_core::arena_bind(A, scratch + scratch_off[slot], 2 * (int32_t)R + 16, 8 * (int32_t)R + 64, (int32_t)R + 8);
+    // the nodes of the runs, a lane per run (what add_node would do one by one in front of the construction)
+    const bool filled = (int32_t)R <= A.node_cap;
+    if (filled) {
+        for (uint32_t r = lane; r < R; r += 64) {
+            const int32_t len = sorted[4 * r + 2];
+            A.row[r] = sorted[4 * r]; A.col[r] = sorted[4 * r + 1]; A.length[r] = len; A.wlen[r] = len;
+            A.incoming[r] = 0; A.deg[r] = 0; A.tail[r] = -1;
+        }
+        __syncthreads();
+    }
     int32_t source = 0, sink = 0, sup[4] = {0, 0, 0, 0}, status = 0, count = 0, R16 = 0;
     int64_t n_edges = 0;
     unsigned long long at = 0;
     if (lane == 0) {
         const int32_t n_levels = (m + n - dist[pid]) / 2;
-        malcs_core::build(A, m, n, shift ? shift[pid] : 0, sorted, (int32_t)R, n_levels, source, sink, sup, malcs_core::no_growth());
+        malcs_core::build(A, m, n, shift ? shift[pid] : 0, sorted, (int32_t)R, n_levels, source, sink, sup, malcs_core::no_growth(), filled);
         status = A.overflow ? 1 : 0;
         bcast[0] = status; bcast[1] = A.n_nodes;
     }

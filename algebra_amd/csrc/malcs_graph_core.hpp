@@ -98,12 +98,14 @@ MALCS_HD void push_edge(arena &A, int32_t node, int32_t child, int32_t start, in
 // On return: A holds the graph, source / sink its end nodes, supremal = {start, end, obs_from, obs_to}.
 template <typename Grow>
 MALCS_HD void build(arena &A, int32_t m, int32_t n, int64_t shift, const int32_t *runs, int32_t n_runs, int32_t n_levels,
-                    int32_t &source, int32_t &sink, int32_t (&supremal)[4], Grow grow)
+                    int32_t &source, int32_t &sink, int32_t (&supremal)[4], Grow grow, bool nodes_filled = false)
 {
     // Level lists: the runs arrive sorted by level, so level L is a contiguous range of node ids (node id == run index);
     // only two lists are alive at a time (the level being emptied and the one below it) -- the reference's list of
     // ~LLCS lists would cost an allocation per level.
-    for (int32_t r = 0; r < n_runs; r++) add_node(A, runs[4 * r], runs[4 * r + 1], runs[4 * r + 2], grow);
+    // (nodes_filled: the caller has made the nodes of the runs already -- the device's wave does, a lane per run)
+    if (nodes_filled && n_runs <= A.node_cap) A.n_nodes = n_runs;
+    else for (int32_t r = 0; r < n_runs; r++) add_node(A, runs[4 * r], runs[4 * r + 1], runs[4 * r + 2], grow);
     if (A.overflow || A.list_cap < 1) { A.overflow = 1; return; }         // node id == run index needs every run in the arena
     int32_t unread = n_runs;                                             // runs [0, unread) are not in a list yet
     const int32_t last = n_runs - 1;                                     // last node of the last level, :379-385
