@@ -1,6 +1,7 @@
 """GPU parity tests: the HIP path (through the C-ABI and the algebra.lcs-shaped facade) against the
 golden fixtures captured from the reference and against the CPU oracle on seeded inputs."""
 
+import os
 import numpy as np
 import pytest
 
@@ -1018,6 +1019,27 @@ def test_graphs_from_two_host_threads_with_a_context_each(native):
             g.close()
         for c in ctxs:
             c.close()
+
+
+def test_randomised_batches_through_every_switch(native):
+    """tools/fuzz_parity.py's batches for fixed seeds: mixed shapes (1 ... 5 000 pairs, 0 ... 5 000 symbols, 2 ... 20 letters,
+    identical to unrelated, tandem repeats), each through one of the nine settings of the switches that pick other kernels
+    (seed mod 9), and a few batches of long pairs: every distance and a sample of graphs against the oracle."""
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("fuzz_parity", os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools", "fuzz_parity.py"))
+    fuzz = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(fuzz)
+    ctx = native.default_context()
+    graphs = 0
+    for seed in range(100, 280):
+        verdict, _, ng = fuzz.check_seed(ctx, seed)
+        assert verdict is None, verdict
+        graphs += ng
+    for seed in range(300, 318):
+        verdict, _, ng = fuzz.check_seed(ctx, seed, long=True)
+        assert verdict is None, verdict
+        graphs += ng
+    assert graphs > 1500
 
 
 @pytest.mark.parametrize("path", ["sweep", "band"])
