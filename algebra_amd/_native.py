@@ -64,6 +64,7 @@ def _load():
         "malcs_graphs_status": (c.c_int, [vp, vp, vp]),
         "malcs_graphs_supremal": (c.c_int, [vp, vp]),
         "malcs_graphs_columns": (c.c_int, [vp, vp, vp, vp, vp]),
+        "malcs_lcs_graph_batch_columns": (c.c_int, [vp, vp, vp, vp, vp, vp, vp, vp]),
         "malcs_graphs_runs": (c.c_int, [vp, u64, vp]),
         "malcs_graphs_nodes": (c.c_int, [vp, u64, vp]),
         "malcs_graphs_edges": (c.c_int, [vp, u64, vp]),
@@ -335,6 +336,12 @@ class Batch:
         if max_distance is not None:
             md = np.ascontiguousarray(max_distance, dtype=np.int64)
         handle = ctypes.c_void_p()
+        if _entry is None and self.n_pairs >= 4096:
+            # graphs and their columns in one call: the pass over the handles runs on the context's threads
+            columns = Graphs.empty_columns(self.n_pairs)
+            check(lib.malcs_lcs_graph_batch_columns(self.handle, ptr(sh) if sh is not None else None, ptr(md) if md is not None else None,
+                                                    ctypes.byref(handle), *(ptr(a) for a in columns)))
+            return Graphs(handle, self.n_pairs, columns=columns)
         check((_entry or lib.malcs_lcs_graph_batch)(self.handle, ptr(sh) if sh is not None else None,
                                                      ptr(md) if md is not None else None, ctypes.byref(handle)))
         return Graphs(handle, self.n_pairs)
@@ -343,21 +350,24 @@ class Batch:
 class Graphs:
     """Result handle of malcs_lcs_graph_batch, read out into numpy arrays."""
 
-    def __init__(self, handle, n_pairs, owner=None):
+    @staticmethod
+    def empty_columns(n_pairs):
+        """counts, status, distance, supremal of n_pairs pairs.  Large handles read their columns into recycled pinned
+        blocks: pages that exist already (fresh numpy arrays of 100 000 pairs cost 0.5 ms of page faults)."""
+        empty = pinned_empty if n_pairs >= 4096 else np.empty
+        return (empty((n_pairs, 4), dtype=np.int64), empty(n_pairs, dtype=np.int32), empty(n_pairs, dtype=np.int64),
+                empty((n_pairs, 4), dtype=np.int64))
+
+    def __init__(self, handle, n_pairs, owner=None, columns=None):
         self.handle = handle
         self.n_pairs = n_pairs
         self.owner = owner                       # set: the handle belongs to that object (a round of VariantGraphs) and lives with it
         _live["graphs"].add(self)
         try:
-            # large handles read their columns into recycled pinned blocks: pages that exist already (fresh numpy
-            # arrays of 100 000 pairs cost 0.5 ms of page faults), filled in one pass over the pairs
-            empty = pinned_empty if n_pairs >= 4096 else np.empty
-            self.counts = empty((n_pairs, 4), dtype=np.int64)
-            self.status = empty(n_pairs, dtype=np.int32)
-            self.distance = empty(n_pairs, dtype=np.int64)
-            self.supremal = empty((n_pairs, 4), dtype=np.int64)
+            # columns: filled already by the call that made the handle; else in one pass over the pairs here
+            self.counts, self.status, self.distance, self.supremal = columns or self.empty_columns(n_pairs)
             self.timing = np.zeros(3, dtype=np.float32)
-            if n_pairs:
+            if n_pairs and columns is None:
                 check(lib.malcs_graphs_columns(handle, ptr(self.counts), ptr(self.status), ptr(self.distance), ptr(self.supremal)))
             check(lib.malcs_graphs_timing(handle, ptr(self.timing)))
             built, ms = ctypes.c_uint64(), ctypes.c_float()

@@ -1313,10 +1313,9 @@ int malcs_graphs_counts(const malcs_graphs *g, int64_t *counts)
 
 // counts, status, distance and supremal in one pass over the pairs (a handle of 100 000 graphs is 20 MB of per-pair
 // records: three passes cost three times the memory traffic)
-int malcs_graphs_columns(const malcs_graphs *g, int64_t *counts, int32_t *status, int64_t *distance, int64_t *supremal4)
+static void columns_of(const malcs_graphs *g, size_t lo, size_t hi, int64_t *counts, int32_t *status, int64_t *distance, int64_t *supremal4)
 {
-    if (!g || !counts || !status || !distance || !supremal4) { malcs_set_error("NULL argument"); return MALCS_ERR_ARG; }
-    for (size_t i = 0; i < g->g.size(); i++) {
+    for (size_t i = lo; i < hi; i++) {
         const pair_graph &G = g->g[i];
         counts[4 * i] = (int64_t)G.n_runs(); counts[4 * i + 1] = G.n_levels;
         counts[4 * i + 2] = (int64_t)G.n_nodes(); counts[4 * i + 3] = (int64_t)G.n_edges();
@@ -1324,6 +1323,29 @@ int malcs_graphs_columns(const malcs_graphs *g, int64_t *counts, int32_t *status
         distance[i] = G.distance;
         for (int k = 0; k < 4; k++) supremal4[4 * i + k] = G.supremal[k];
     }
+}
+
+int malcs_graphs_columns(const malcs_graphs *g, int64_t *counts, int32_t *status, int64_t *distance, int64_t *supremal4)
+{
+    if (!g || !counts || !status || !distance || !supremal4) { malcs_set_error("NULL argument"); return MALCS_ERR_ARG; }
+    columns_of(g, 0, g->g.size(), counts, status, distance, supremal4);
+    return MALCS_OK;
+}
+
+// malcs_lcs_graph_batch + malcs_graphs_columns in one call: the pass over the handles of a large batch (20 MB per 100 000
+// pairs that have just left the cache: 0.9 ms on one thread) is shared among the context's threads
+int malcs_lcs_graph_batch_columns(malcs_batch *b, const int64_t *shift, const int64_t *max_distance, malcs_graphs **graphs,
+                                  int64_t *counts, int32_t *status, int64_t *distance, int64_t *supremal4)
+{
+    if (!counts || !status || !distance || !supremal4) { malcs_set_error("NULL argument"); return MALCS_ERR_ARG; }
+    const int rc = malcs_lcs_graph_batch(b, shift, max_distance, graphs);
+    if (rc) return rc;
+    const malcs_graphs *g = *graphs;
+    const size_t N = g->g.size();
+    malcs_workers *wk = N >= 16384 ? malcs_ctx_workers(b->ctx) : nullptr;
+    const int nt = wk ? (int)std::min<size_t>(16, wk->size()) : 1;
+    if (nt > 1) wk->run(nt, [&](int t) { columns_of(g, N * (size_t)t / (size_t)nt, N * (size_t)(t + 1) / (size_t)nt, counts, status, distance, supremal4); });
+    else columns_of(g, 0, N, counts, status, distance, supremal4);
     return MALCS_OK;
 }
 

@@ -231,6 +231,10 @@ int malcs_graphs_status(const malcs_graphs *graphs, int32_t *status, int64_t *di
 int malcs_graphs_supremal(const malcs_graphs *graphs, int64_t *supremal4);
 /* the three calls above in one pass over the pairs (what the facade reads out of every handle) */
 int malcs_graphs_columns(const malcs_graphs *graphs, int64_t *counts, int32_t *status, int64_t *distance, int64_t *supremal4);
+/* malcs_lcs_graph_batch and malcs_graphs_columns in one call (same arguments, same results): the pass over the pairs of
+ * a large batch runs on the context's threads instead of the caller's one. */
+int malcs_lcs_graph_batch_columns(malcs_batch *batch, const int64_t *shift, const int64_t *max_distance, malcs_graphs **graphs,
+                                  int64_t *counts, int32_t *status, int64_t *distance, int64_t *supremal4);
 /* fill caller buffers for pair i (sizes from malcs_graphs_counts) */
 int malcs_graphs_runs(const malcs_graphs *graphs, uint64_t i, int64_t *runs4);
 int malcs_graphs_nodes(const malcs_graphs *graphs, uint64_t i, int64_t *nodes3);
